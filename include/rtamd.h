@@ -1,0 +1,219 @@
+/*
+ * rtamd.h — C ABI of the MI355X (gfx950) ray-tracing backend.
+ *
+ * This is the drop-in boundary for the compute path of houshuo/RayTracing:
+ * the library accepts the project's own scene buffers byte-for-byte (the
+ * arrays `BuildAccelerateStructureSystem` uploads with ComputeBuffer.SetData)
+ * plus the per-frame constant buffer that `RayTracingPass.Execute` fills, and
+ * renders with hand-written HIP kernels.  Every entry point is `extern "C"`,
+ * takes plain pointers / sizes / blittable structs only, returns an int
+ * status (0 = ok, negative = error) and never throws across the boundary.
+ *
+ * Reference interfaces replaced (paths relative to the reference checkout):
+ *   struct layouts   Assets/Script/Common/RayTraceMaterial.cs:6-35,
+ *                    Assets/Script/BVH/BoundingVolumeHierarchyBuilder.cs:31-37,
+ *                    Assets/Script/BVH/Base/Math/FourTransposedAabbs.cs:6-10,
+ *                    mirrored in Assets/Shaders/RayTracingShader.compute:8-19,80-124
+ *   scene bindings   Assets/Script/RenderPass/RayTracingPass.cs:83-97
+ *   dispatch         Assets/Script/RenderPass/RayTracingPass.cs:101
+ */
+#ifndef RTAMD_H
+#define RTAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* Wire structs — byte-identical to the reference (all members 4-byte) */
+/* ------------------------------------------------------------------ */
+
+/* BoundingVolumeHierarchy.Node (BoundingVolumeHierarchyBuilder.cs:31-37,
+ * RayTracingShader.compute:80-91).  116 bytes.  Lane i of every bound = child i.
+ * Flags == 0: internal, Data[i] = child node index relative to the tree base,
+ * 0 = empty slot.  Flags != 0: leaf, Data[i] = primitive index, -1 = empty.
+ * Node 0 is a sentinel, the root is node 1. */
+typedef struct rtamd_node {
+    float   Lx[4], Hx[4];
+    float   Ly[4], Hy[4];
+    float   Lz[4], Hz[4];
+    int32_t Data[4];
+    int32_t Flags;
+} rtamd_node;
+
+/* Vertex (RayTraceMaterial.cs:6-10, RayTracingShader.compute:102-106). 24 bytes. */
+typedef struct rtamd_vertex {
+    float position[3];
+    float normal[3];
+} rtamd_vertex;
+
+/* int3 triangle (RayTracableComponent.cs:15, RayTracingShader.compute:109). 12 bytes.
+ * Vertex indices relative to the mesh's vertex base. */
+typedef struct rtamd_int3 {
+    int32_t x, y, z;
+} rtamd_int3;
+
+/* PerObjectProperty (RayTraceMaterial.cs:19-25, RayTracingShader.compute:117-123).
+ * 180 bytes.  Matrices are column-major: 4 consecutive floats = one column. */
+typedef struct rtamd_object_property {
+    int32_t BLASIndex;
+    float   albedo[4];
+    float   specular[4];
+    float   emission[4];
+    float   WorldToLocal[16];
+    float   LocalToWorld[16];
+} rtamd_object_property;
+
+/* FrameCBuffer (RayTraceMaterial.cs:28-35, RayTracingShader.compute:8-19). 144 bytes. */
+typedef struct rtamd_frame_cbuffer {
+    float   CameraToWorld[16];
+    float   CameraInverseProjection[16];
+    float   PixelOffset[2];
+    float   Seed;
+    int32_t ReflectionNum;
+} rtamd_frame_cbuffer;
+
+/* ------------------------------------------------------------------ */
+/* Extension parameters (no counterpart in the reference cbuffer)      */
+/* ------------------------------------------------------------------ */
+
+enum {
+    RTAMD_MODE_REF = 0, /* RayTracingShader.compute:413-429 exactly: primary + one mirror bounce */
+    RTAMD_MODE_PT  = 1  /* bounced path tracing grown from the shader's unused roulette code (:386-411) */
+};
+
+enum {
+    RTAMD_FLAG_ACCUMULATE      = 1 << 0, /* PT: add this call's samples to the context's running sum */
+    RTAMD_FLAG_NO_JITTER       = 1 << 1, /* PT: use FrameCBuffer.PixelOffset instead of a random sub-pixel offset */
+    RTAMD_FLAG_REFERENCE_ORDER = 1 << 2, /* traverse in the reference's exact node order on the reference's own node layout */
+    RTAMD_FLAG_OUTPUT_SUM      = 1 << 3, /* PT: write the un-normalised sample sum (for cross-GPU sample sharding) */
+    RTAMD_FLAG_COUNTERS        = 1 << 4  /* also fill the work counters (forces REFERENCE_ORDER so the counts are the reference's) */
+};
+
+/* Work counters, summed over every ray segment of one render call. */
+typedef struct rtamd_counters {
+    uint64_t rays;            /* ray segments traversed (primary + every bounce) */
+    uint64_t nodes;           /* BVH nodes fetched, TLAS + BLAS */
+    uint64_t tris;            /* triangles tested */
+    uint64_t instances;       /* BLAS entries (object property fetches) */
+    uint64_t hits;            /* accepted (closer) hits */
+    uint64_t max_blas_stack;  /* deepest BLAS stack seen */
+    uint64_t max_tlas_stack;  /* deepest TLAS stack seen */
+    uint64_t reserved;
+} rtamd_counters;
+
+typedef struct rtamd_ext_params {
+    uint32_t struct_size;   /* = sizeof(rtamd_ext_params) */
+    int32_t  mode;          /* RTAMD_MODE_* */
+    int32_t  spp;           /* PT: samples per pixel rendered by this call (>=1) */
+    int32_t  max_bounces;   /* PT: scattering events after the primary segment (segments <= max_bounces+1) */
+    uint64_t seed;          /* PT: RNG seed; the stream is keyed (seed, pixel, sample, bounce, dimension) */
+    int32_t  sample_offset; /* PT: index of the first sample of this call */
+    int32_t  tile_x, tile_y, tile_w, tile_h; /* render only this pixel rectangle (tile_w<=0 or tile_h<=0: whole image) */
+    int32_t  shard_rank, shard_count;        /* render only 32x32 tiles t with t % shard_count == shard_rank (count<=1: all) */
+    uint32_t flags;         /* RTAMD_FLAG_* */
+    float*   out_t;         /* optional, width*height floats: primary hit parameter t (+inf on miss) */
+    rtamd_counters* out_counters; /* optional (host pointer) */
+} rtamd_ext_params;
+
+/* ------------------------------------------------------------------ */
+/* Status codes                                                         */
+/* ------------------------------------------------------------------ */
+enum {
+    RTAMD_OK                 =  0,
+    RTAMD_ERR_INVALID_ARG    = -1,
+    RTAMD_ERR_BAD_INDEX      = -2, /* an offset / index in the uploaded buffers is out of range */
+    RTAMD_ERR_OUT_OF_MEMORY  = -3,
+    RTAMD_ERR_HIP            = -4,
+    RTAMD_ERR_STACK_OVERFLOW = -5, /* traversal needed more stack than the reference shader declares (:93-94) */
+    RTAMD_ERR_NO_SCENE       = -6, /* render before a scene upload (the reference skips the dispatch: RayTracingPass.cs:68) */
+    RTAMD_ERR_NO_DEVICE      = -7
+};
+
+typedef struct rtamd_ctx rtamd_ctx;
+
+/* Replaces the ComputeShader / ComputeBuffer ownership of RayTracingPass.Create
+ * (RayTracingPass.cs:119-125) and BuildAccelerateStructureSystem.OnCreate (:35-39). */
+int rtamd_ctx_create(int device_ordinal, rtamd_ctx** out_ctx);
+
+/* Replaces RayTracingPass.Dispose (:137-145) and BuildAccelerateStructureSystem.OnDestroy (:165-176). */
+int rtamd_ctx_destroy(rtamd_ctx* ctx);
+
+/* Last error text of this context (or of ctx creation when ctx is NULL). Never NULL. */
+const char* rtamd_last_error_string(const rtamd_ctx* ctx);
+
+/* Replaces the eight ComputeBuffer.SetData calls of
+ * BuildAccelerateStructureSystem.OnUpdate (BuildAccelerateStructureSystem.cs:124-158)
+ * and the eight SetComputeBufferParam bindings of RayTracingPass.Execute (:87-97).
+ * All pointers are host memory in the reference layouts; the library copies
+ * (and re-packs for the GPU) before returning.  n_tlas_nodes may include the
+ * reference's uninitialised tail (TopLevelAccelerateStructure.cs:17,30): only
+ * nodes reachable from node 1 are read. */
+int rtamd_scene_upload(rtamd_ctx* ctx,
+                       const rtamd_node* tlas, int32_t n_tlas_nodes,
+                       const int32_t* blas_offsets,
+                       const rtamd_node* blas, int32_t n_blas_nodes,
+                       const int32_t* vertices_offsets,
+                       const rtamd_vertex* vertices, int32_t n_vertices,
+                       const int32_t* triangles_offsets,
+                       const rtamd_int3* triangles, int32_t n_triangles,
+                       int32_t n_blas,
+                       const rtamd_object_property* objects, int32_t n_objects);
+
+/* Cheap per-frame refresh for moving objects: replaces only _TLAS and
+ * _ObjectsProperty (the reference re-uploads everything each frame,
+ * BuildAccelerateStructureSystem.cs:148-158; the meshes are static). n_objects
+ * must equal the uploaded scene's. */
+int rtamd_scene_refresh_objects(rtamd_ctx* ctx,
+                                const rtamd_node* tlas, int32_t n_tlas_nodes,
+                                const rtamd_object_property* objects, int32_t n_objects);
+
+/* Replaces SetComputeTextureParam(.., "_SkyboxTexture", ..) (RayTracingPass.cs:85).
+ * rgba32f: height rows of width RGBA float texels, row 0 = v 0.  Sampled
+ * bilinear, repeat, mip 0 (Assets/SkyBoxes/dikhololo_night_4k.exr.meta:33,36,39-40).
+ * Without a sky the miss colour is black. */
+int rtamd_sky_upload(rtamd_ctx* ctx, const float* rgba32f, int32_t width, int32_t height);
+
+/* Replaces cmd.DispatchCompute(shader, 0, RTWidth, RTHeight, 1)
+ * (RayTracingPass.cs:101) together with the Result binding (:99).
+ *   frame        the reference cbuffer, required.
+ *   ext          NULL = RTAMD_MODE_REF with defaults.
+ *   out_rgba     optional, width*height*4 floats, row-major, row 0 = uv.y -1
+ *                (RayTracingShader.compute:439).  Host or device pointer.
+ *   out_prim_id  optional, width*height*2 int32: (object index, triangle index)
+ *                of the un-jittered primary hit, (-1,-1) on miss.  Host or device.
+ * Blocking: returns after the image is complete.  Pixels outside the tile
+ * rectangle / shard are left untouched. */
+int rtamd_render(rtamd_ctx* ctx, const rtamd_frame_cbuffer* frame,
+                 const rtamd_ext_params* ext, int32_t width, int32_t height,
+                 float* out_rgba, int32_t* out_prim_id);
+
+/* Drop the running sum used by RTAMD_FLAG_ACCUMULATE. */
+int rtamd_accum_reset(rtamd_ctx* ctx);
+
+/* Run kernels of this context on a caller-owned HIP stream (hipStream_t as
+ * void*; NULL = the context's own stream). */
+int rtamd_set_stream(rtamd_ctx* ctx, void* hip_stream);
+
+/* Device time of the traversal kernel(s) of the last rtamd_render call,
+ * measured with HIP events on the launch stream, and the number of ray
+ * segments it traced. */
+int rtamd_last_render_stats(const rtamd_ctx* ctx, float* kernel_ms, uint64_t* ray_segments);
+
+/* Presentation step of the reference: AddShader's `Blend SrcAlpha One`
+ * (Assets/Shaders/AddShader.shader:11,43-46) onto an 8-bit UNORM target
+ * (RayTracingPass.cs:58): dst = saturate(dst + src.rgb * src.a), quantised to
+ * 8 bits.  src_rgba: width*height*4 floats, dst_rgba8: width*height*4 bytes,
+ * both host or both device. */
+int rtamd_composite_add(rtamd_ctx* ctx, const float* src_rgba, uint8_t* dst_rgba8,
+                        int32_t width, int32_t height);
+
+/* Library / build identification, e.g. "rtamd 0.1 gfx950". */
+const char* rtamd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTAMD_H */

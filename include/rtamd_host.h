@@ -1,0 +1,150 @@
+/*
+ * rtamd_host.h — C ABI of the host-side scene producers (CPU only, no GPU calls).
+ *
+ * These functions stand in for the C# host code that feeds the compute path of
+ * houshuo/RayTracing when Unity is not available: the 4-wide BVH builder, the
+ * edit-time BLAS bake, the per-frame acceleration-structure system that
+ * flattens everything into the eight buffers of rtamd_scene_upload, Unity's
+ * camera matrices, and mesh sources (generators, COLLADA, subdivision).
+ * In a Unity build the project's own C# code produces the same buffers and this
+ * library is not needed.
+ *
+ * Reference code restated (paths relative to the reference checkout):
+ *   Assets/Script/BVH/BoundingVolumeHierarchyBuilder.cs      (builder, Refit)
+ *   Assets/Script/BVH/Base/Math/{Aabb,FourTransposedAabbs,Math}.cs
+ *   Assets/Editor/RayTracing/Authoring/RayTraceableBaker.cs:75-149
+ *   Assets/Script/RayTracing/System/BuildAccelerateStructureSystem.cs:41-163,202-300
+ *   Assets/Script/RayTracing/Component/TopLevelAccelerateStructure.cs
+ */
+#ifndef RTAMD_HOST_H
+#define RTAMD_HOST_H
+
+#include <stdint.h>
+#include "rtamd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Aabb (Aabb.cs:11-14): Min then Max. */
+typedef struct rtamd_aabb { float Min[3]; float Max[3]; } rtamd_aabb;
+/* BoundingVolumeHierarchy.PointAndIndex (BoundingVolumeHierarchyBuilder.cs:87-91). */
+typedef struct rtamd_point_and_index { float Position[3]; int32_t Index; } rtamd_point_and_index;
+
+/* BoundingVolumeHierarchy.Build (BoundingVolumeHierarchyBuilder.cs:529-558), median
+ * split (useSah = false, the only mode any caller uses).  `points` is permuted in
+ * place, as in the reference.  `nodes` must hold n + 64 entries
+ * (RayTraceableBaker.cs:129).  Returns 0 or a negative rtamd status. */
+int rtamd_host_bvh_build(rtamd_point_and_index* points, const rtamd_aabb* aabbs, int32_t n,
+                         rtamd_node* nodes, int32_t nodes_capacity, int32_t* node_count);
+
+/* BoundingVolumeHierarchy.ScheduleBuildJobs (:482-527) run to completion:
+ * BuildFirstNLevelsJob, every BuildBranchesJob, FinalizeTreeJob.  This is the
+ * TLAS build path (TopLevelAccelerateStructure.cs:64-68).  `nodes` must hold
+ * n + 64 entries; entries the build does not reach are left zeroed.
+ * branch_count receives the number of branches. */
+int rtamd_host_bvh_build_jobs(rtamd_point_and_index* points, const rtamd_aabb* aabbs, int32_t n,
+                              rtamd_node* nodes, int32_t nodes_capacity, int32_t* branch_count);
+
+/* A better tree over the same primitives, in the same node format: binned
+ * surface-area-heuristic splits (what the reference's unused SAH path, :166-260,
+ * aims at).  Interchangeable with rtamd_host_bvh_build for any consumer. */
+int rtamd_host_bvh_build_sah(const rtamd_aabb* aabbs, int32_t n,
+                             rtamd_node* nodes, int32_t nodes_capacity, int32_t* node_count);
+
+/* ------------------------------------------------------------------ */
+/* Scene assembly: the ECS world + BuildAccelerateStructureSystem       */
+/* ------------------------------------------------------------------ */
+typedef struct rtamd_host_scene rtamd_host_scene;
+
+rtamd_host_scene* rtamd_host_scene_create(void);
+void rtamd_host_scene_destroy(rtamd_host_scene* s);
+
+/* BLASBaker.BuildBLASBlobAssetReference (RayTraceableBaker.cs:75-149): copies
+ * the mesh, builds per-triangle AABBs + centres and the BLAS.  tree = 0: the
+ * reference's median builder, 1: the SAH builder.  Returns the blob handle
+ * (>= 0) or a negative status.  Baking the same mesh once and instancing the
+ * handle is the reference's blob de-duplication (:59-65). */
+int rtamd_host_bake_blas(rtamd_host_scene* s, const float* positions, const float* normals,
+                         int32_t n_vertices, const int32_t* indices, int32_t n_triangles, int32_t tree);
+
+/* One entity with RayTraceableBLASComponent + RayTraceableMaterialComponent +
+ * LocalToWorld (column-major).  Returns the entity index (= object index =
+ * entityIndexInQuery) or a negative status. */
+int rtamd_host_add_entity(rtamd_host_scene* s, int32_t blas_handle, const float local_to_world[16],
+                          const float albedo[4], const float specular[4], const float emission[4]);
+int rtamd_host_set_entity_transform(rtamd_host_scene* s, int32_t entity, const float local_to_world[16]);
+
+/* BuildAccelerateStructureSystem.OnUpdate (:41-163): world AABBs, TLAS build,
+ * BLAS index assignment by first use, offsets, flattening, object properties
+ * (WorldToLocal = inverse(LocalToWorld)). */
+int rtamd_host_scene_update(rtamd_host_scene* s);
+
+typedef struct rtamd_host_buffers {
+    const rtamd_node* tlas; int32_t n_tlas_nodes;
+    const int32_t* blas_offsets;
+    const rtamd_node* blas; int32_t n_blas_nodes;
+    const int32_t* vertices_offsets;
+    const rtamd_vertex* vertices; int32_t n_vertices;
+    const int32_t* triangles_offsets;
+    const rtamd_int3* triangles; int32_t n_triangles;
+    int32_t n_blas;
+    const rtamd_object_property* objects; int32_t n_objects;
+    int32_t tlas_branch_count;
+} rtamd_host_buffers;
+
+/* The eight buffers of the last update; valid until the next update / destroy. */
+int rtamd_host_scene_buffers(const rtamd_host_scene* s, rtamd_host_buffers* out);
+
+/* ------------------------------------------------------------------ */
+/* Camera and math                                                      */
+/* ------------------------------------------------------------------ */
+
+/* camera.cameraToWorldMatrix and camera.projectionMatrix.inverse
+ * (RayTracingPass.cs:74-75) for a Unity camera: position, rotation quaternion
+ * (x,y,z,w), vertical field of view in degrees, aspect = width/height, near,
+ * far.  Unity / OpenGL convention: the camera looks down -Z of camera space. */
+void rtamd_host_camera(const float position[3], const float rotation_xyzw[4], float fov_y_deg,
+                       float aspect, float z_near, float z_far, rtamd_frame_cbuffer* out);
+
+/* General 4x4 inverse (column-major), the stand-in for math.inverse
+ * (BuildAccelerateStructureSystem.cs:297).  Returns 0, or -1 if singular. */
+int rtamd_host_inverse4x4(const float m[16], float out[16]);
+
+/* TRS matrix (column-major) from translation, rotation quaternion (x,y,z,w), scale. */
+void rtamd_host_trs(const float t[3], const float q_xyzw[4], const float s[3], float out[16]);
+
+/* ------------------------------------------------------------------ */
+/* Mesh sources                                                         */
+/* ------------------------------------------------------------------ */
+typedef struct rtamd_host_mesh {
+    float* positions;  /* 3 * n_vertices */
+    float* normals;    /* 3 * n_vertices */
+    int32_t n_vertices;
+    int32_t* indices;  /* 3 * n_triangles */
+    int32_t n_triangles;
+} rtamd_host_mesh;
+
+void rtamd_host_mesh_free(rtamd_host_mesh* m);
+/* UV sphere of the given radius: `segments` around, `rings` pole to pole. */
+int rtamd_host_mesh_uv_sphere(int32_t segments, int32_t rings, float radius, rtamd_host_mesh* out);
+/* Unit quad in the XY plane facing -Z (Unity's built-in Quad), 2 triangles. */
+int rtamd_host_mesh_quad(rtamd_host_mesh* out);
+/* Unit cube centred at the origin, 12 triangles, per-face normals. */
+int rtamd_host_mesh_cube(rtamd_host_mesh* out);
+/* COLLADA <triangles> mesh (VERTEX/NORMAL index pairs).  A Z_UP asset is rotated to Y-up. */
+int rtamd_host_mesh_load_dae(const char* path, rtamd_host_mesh* out);
+/* Midpoint subdivision, every triangle -> 4, `rounds` times. */
+int rtamd_host_mesh_subdivide(const rtamd_host_mesh* in, int32_t rounds, rtamd_host_mesh* out);
+
+/* Flattened-scene file: the eight arrays behind a small header.  Save returns 0. */
+int rtamd_host_scene_save(const rtamd_host_buffers* b, const char* path);
+/* Load into a scene object (replaces its buffers; no entities are recreated). */
+int rtamd_host_scene_load(rtamd_host_scene* s, const char* path);
+
+const char* rtamd_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTAMD_HOST_H */

@@ -1,0 +1,75 @@
+"""Compile the native libraries in-tree.
+
+  raytracing_amd/lib/librtamd.so       HIP kernels + C ABI (hipcc, gfx950 only)
+  raytracing_amd/lib/librtamd_host.so  host-side scene producers (g++, CPU only)
+  oracle/_build/librt_oracle.so        CPU oracle (g++; test infrastructure)
+
+Run as `python -m raytracing_amd.build` or through `__graft_entry__.build()`.
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "raytracing_amd", "csrc")
+LIB = os.path.join(ROOT, "raytracing_amd", "lib")
+INC = os.path.join(ROOT, "include")
+
+# -ffp-contract=off: the kernels and the oracle must round every product and sum
+# separately so that both give the same bits.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+CXX_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-pthread",
+             "-Wall", "-Wno-misleading-indentation"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+
+
+def build_device(force=False):
+    src = os.path.join(CSRC, "rtamd.hip")
+    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps += [os.path.join(INC, "rtamd.h")]
+    out = os.path.join(LIB, "librtamd.so")
+    if force or _newer(out, deps):
+        os.makedirs(LIB, exist_ok=True)
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        _run([hipcc] + HIP_FLAGS + ["-I" + INC, "-I" + CSRC, src, "-o", out])
+    return out
+
+
+def build_host(force=False):
+    hdir = os.path.join(CSRC, "host")
+    srcs = sorted(os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".cpp"))
+    deps = srcs + [os.path.join(hdir, "host_internal.h"), os.path.join(INC, "rtamd.h"), os.path.join(INC, "rtamd_host.h")]
+    out = os.path.join(LIB, "librtamd_host.so")
+    if force or _newer(out, deps):
+        os.makedirs(LIB, exist_ok=True)
+        _run([os.environ.get("CXX", "g++")] + CXX_FLAGS + ["-I" + INC, "-I" + hdir] + srcs + ["-o", out])
+    return out
+
+
+def build_oracle(force=False):
+    odir = os.path.join(ROOT, "oracle")
+    src = os.path.join(odir, "rt_oracle.cpp")
+    out = os.path.join(odir, "_build", "librt_oracle.so")
+    if force or _newer(out, [src]):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        _run([os.environ.get("CXX", "g++")] + CXX_FLAGS + [src, "-o", out])
+    return out
+
+
+def build_all(force=False):
+    return build_device(force), build_host(force), build_oracle(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,198 @@
+// Device-side structs and the shading / sampling code shared by both traversal kernels.
+#pragma once
+
+#include "device_math.h"
+#include "rtamd.h"
+
+namespace rt {
+
+// The reference's buffers exactly as uploaded (RayTracingShader.compute:96-124).
+struct RefScene {
+    const rtamd_node* tlas;
+    const int32_t* blasOffsets;
+    const rtamd_node* blas;
+    const int32_t* vtxOffsets;
+    const rtamd_vertex* verts;
+    const int32_t* triOffsets;
+    const rtamd_int3* tris;
+    const rtamd_object_property* objects;
+};
+
+struct Sky {
+    const float4* texels;
+    int32_t w, h;
+};
+
+struct DevCounters {
+    unsigned long long rays, nodes, tris, instances, hits, maxBlasStack, maxTlasStack, overflow;
+};
+
+struct RenderArgs {
+    rtamd_frame_cbuffer cb;
+    int32_t width, height;
+    int32_t mode, spp, maxBounces;
+    uint32_t seedHi, seedLo;
+    int32_t sampleOffset;
+    int32_t tileX, tileY, tileW, tileH;   // already clipped to the image
+    int32_t shardRank, shardCount;
+    uint32_t flags;
+    float4* outRgba;        // may be null
+    int32_t* outIds;        // may be null, 2 per pixel
+    float* outT;            // may be null
+    float4* accum;          // running sums (ACCUMULATE), may be null
+    float accumSamplesBefore;   // samples already in accum before this call
+    DevCounters* counters;  // may be null
+    unsigned long long* rayCount;   // always valid
+    int32_t* errorFlag;     // always valid
+};
+
+struct Ray { V3 origin, direction, invDir; };
+
+__device__ __forceinline__ Ray makeRay(V3 o, V3 d) {          // CreateRay, .compute:135-143
+    Ray r;
+    r.origin = o;
+    r.direction = d;
+    r.invDir = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    return r;
+}
+
+__device__ __forceinline__ Ray cameraRay(const rtamd_frame_cbuffer& cb, float u, float v) {   // .compute:145-157
+    V3 origin = v3(cb.CameraToWorld[12], cb.CameraToWorld[13], cb.CameraToWorld[14]);
+    const float* ip = cb.CameraInverseProjection;
+    V3 d = v3(((ip[0] * u + ip[4] * v) + ip[8] * 0.0f) + ip[12],
+              ((ip[1] * u + ip[5] * v) + ip[9] * 0.0f) + ip[13],
+              ((ip[2] * u + ip[6] * v) + ip[10] * 0.0f) + ip[14]);
+    d = mulDir(cb.CameraToWorld, d);
+    d = normalize(d);
+    return makeRay(origin, d);
+}
+
+// uv = (id.xy + offset) / (w,h) * 2 - 1.  .compute:439
+__device__ __forceinline__ float pixelToNdc(int p, float offset, int extent) {
+    return ((float)p + offset) / (float)extent * 2.0f - 1.0f;
+}
+
+// Culled Möller–Trumbore.  .compute:198-231.  e1 = v1 - v0, e2 = v2 - v0.
+__device__ __forceinline__ bool trisect(V3 org, V3 dir, V3 v0, V3 e1, V3 e2, float& T, float& U, float& V) {
+    V3 pvec = cross(dir, e2);
+    float det = dot(e1, pvec);
+    if (det < RT_EPSILON) return false;
+    float inv_det = 1.0f / det;
+    V3 tvec = org - v0;
+    float u = dot(tvec, pvec) * inv_det;
+    if (u < 0.0f || u > 1.0f) return false;
+    V3 qvec = cross(tvec, e1);
+    float v = dot(dir, qvec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = dot(e2, qvec) * inv_det;
+    if (t > 0) { T = t; U = u; V = v; return true; }
+    return false;
+}
+
+// Bilinear, repeat, mip 0.  .compute:409
+__device__ __forceinline__ V3 sampleSky(const Sky& sky, float u, float v) {
+    if (!sky.texels) return v3(0, 0, 0);
+    float W = (float)sky.w, H = (float)sky.h;
+    float x = u * W - 0.5f;
+    float y = v * H - 0.5f;
+    float x0f = __builtin_floorf(x), y0f = __builtin_floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    float xw = x0f - __builtin_floorf(x0f / W) * W;
+    float yw = y0f - __builtin_floorf(y0f / H) * H;
+    int x0 = (int)xw, y0 = (int)yw;
+    if (x0 < 0) x0 = 0;
+    if (x0 >= sky.w) x0 = sky.w - 1;
+    if (y0 < 0) y0 = 0;
+    if (y0 >= sky.h) y0 = sky.h - 1;
+    int x1 = x0 + 1 == sky.w ? 0 : x0 + 1;
+    int y1 = y0 + 1 == sky.h ? 0 : y0 + 1;
+    float4 p00 = sky.texels[(size_t)y0 * sky.w + x0];
+    float4 p10 = sky.texels[(size_t)y0 * sky.w + x1];
+    float4 p01 = sky.texels[(size_t)y1 * sky.w + x0];
+    float4 p11 = sky.texels[(size_t)y1 * sky.w + x1];
+    float gx = 1.0f - fx, gy = 1.0f - fy;
+    V3 r;
+    r.x = (p00.x * gx + p10.x * fx) * gy + (p01.x * gx + p11.x * fx) * fy;
+    r.y = (p00.y * gx + p10.y * fx) * gy + (p01.y * gx + p11.y * fx) * fy;
+    r.z = (p00.z * gx + p10.z * fx) * gy + (p01.z * gx + p11.z * fx) * fy;
+    return r;
+}
+
+// Miss branch of Shade.  .compute:402-410
+__device__ __forceinline__ V3 shadeMiss(const Sky& sky, V3 dir) {
+    float theta = acosDecl(dir.y) / -RT_PI;
+    float phi = atan2Decl(dir.x, -dir.z) / -RT_PI * 0.5f;
+    return sampleSky(sky, phi, theta);
+}
+
+__device__ __forceinline__ float energyOf(V3 c) {             // .compute:45-48
+    const float third = 1.0f / 3.0f;
+    return (c.x * third + c.y * third) + c.z * third;
+}
+
+// Uniform hemisphere sample around `normal`.  .compute:33-43, 67-76
+__device__ __forceinline__ V3 sampleHemisphere(V3 normal, float u1, float u2) {
+    float cosTheta = u1;
+    float sinTheta = __builtin_sqrtf(fmax_(0.0f, 1.0f - cosTheta * cosTheta));
+    float sphi, cphi;
+    sincos2piDecl(u2, sphi, cphi);
+    V3 ts = v3(cphi * sinTheta, sphi * sinTheta, cosTheta);
+    V3 helper = v3(1, 0, 0);
+    if (__builtin_fabsf(normal.x) > 0.99f) helper = v3(0, 0, 1);
+    V3 tangent = normalize(cross(normal, helper));
+    V3 binormal = normalize(cross(normal, tangent));
+    return ((ts.x * tangent) + (ts.y * binormal)) + (ts.z * normal);
+}
+
+// One scattering event of the path tracer: the specular / diffuse roulette the shader's
+// Shade sketches (.compute:391-399).  Returns false when the path ends.
+__device__ __forceinline__ bool scatter(V3 albedoIn, V3 spec, V3 normal, V3 inDir, uint32_t key, uint32_t bounce,
+                                        V3& energy, V3& outDir) {
+    V3 alb = v3(fmin_(1.0f - spec.x, albedoIn.x), fmin_(1.0f - spec.y, albedoIn.y), fmin_(1.0f - spec.z, albedoIn.z));
+    float specChance = energyOf(spec);
+    float diffChance = energyOf(alb);
+    float sum = specChance + diffChance;
+    if (!(sum > 0.0f)) return false;
+    specChance = specChance / sum;
+    diffChance = diffChance / sum;
+    float roulette = rngDraw(key, 2u + 3u * bounce);
+    if (roulette < specChance) {
+        outDir = reflect(inDir, normal);
+        energy = energy * (((1.0f / specChance) * spec) * saturate(dot(normal, outDir)));
+    } else {
+        float u1 = rngDraw(key, 3u + 3u * bounce);
+        float u2 = rngDraw(key, 4u + 3u * bounce);
+        outDir = sampleHemisphere(normal, u1, u2);
+        energy = energy * ((((1.0f / diffChance) * 2.0f) * alb) * saturate(dot(normal, outDir)));
+    }
+    return energy.x > 0.0f || energy.y > 0.0f || energy.z > 0.0f;
+}
+
+__device__ __forceinline__ bool pixelSelected(const RenderArgs& a, int x, int y) {
+    if (x < a.tileX || y < a.tileY || x >= a.tileX + a.tileW || y >= a.tileY + a.tileH) return false;
+    if (a.shardCount > 1) {
+        int tilesX = (a.width + 31) / 32;
+        int tile = (y / 32) * tilesX + (x / 32);
+        if (tile % a.shardCount != a.shardRank) return false;
+    }
+    return true;
+}
+
+// Final write of a path-traced pixel: plain mean, running mean with the context's
+// accumulation buffer, or the raw sum.
+__device__ __forceinline__ void writePathPixel(const RenderArgs& a, size_t pix, V3 sum) {
+    float n = (float)a.spp;
+    if (a.accum) {
+        float4 acc = a.accum[pix];
+        acc.x += sum.x; acc.y += sum.y; acc.z += sum.z; acc.w += n;
+        a.accum[pix] = acc;
+        sum = v3(acc.x, acc.y, acc.z);
+        n = acc.w;
+    }
+    if (a.outRgba) {
+        if (a.flags & RTAMD_FLAG_OUTPUT_SUM) a.outRgba[pix] = make_float4(sum.x, sum.y, sum.z, n);
+        else a.outRgba[pix] = make_float4(sum.x / n, sum.y / n, sum.z / n, 1.0f);
+    }
+}
+
+}  // namespace rt

@@ -1,0 +1,654 @@
+// Production path: GPU-side scene layout, its construction at upload time, and the
+// persistent traversal + shading kernel.
+//
+// What the kernel must reproduce is fixed by Assets/Shaders/RayTracingShader.compute:
+// the closest front-facing triangle along each ray with the arithmetic of Trisection
+// (:198-231) in the instance's local space (:287), and — when two triangles give the
+// same t bit for bit — the one the reference's fixed visiting order reaches first
+// (strict '<' at :327).  It does NOT have to visit nodes in the reference's order:
+//   * triangles and instances are stored in the order the reference's depth-first walk
+//     would reach them, so "reached first" is "smaller index" and ties are broken by
+//     index, independent of the traversal order used here;
+//   * box tests of internal nodes only prune by distance, so nodes are visited nearest
+//     first; the reference's 4-triangle leaf NODES are folded into their parent, but each
+//     triangle keeps its leaf-slot box and is tested only if the reference's slab test
+//     (:233-263) of that box passes with the distance on entry to the leaf — a ray lying
+//     exactly in a box face makes that test fail (0 * inf = NaN is ignored by min/max),
+//     and the reference then never sees the triangle.
+//
+// Layout (all arrays 128-byte aligned in HBM):
+//   WNode  128 B  lx,hx,ly,hy,lz,hz (float4 = the four children), child[4], pad
+//   FTri    64 B  (v0, original index) (e1, lo.x) (e2, lo.y) (lo.z, hi) — in reference visiting order
+//   FNrm    48 B  n0,n1,n2                                   — read once per closest hit
+//   FInst   64 B  three rows of WorldToLocal, BLAS root, original object index
+//   FShade  96 B  three rows of LocalToWorld, albedo, specular, emission
+#pragma once
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernel_common.h"
+
+namespace rt {
+
+struct alignas(128) WNode {
+    float4 lx, hx, ly, hy, lz, hz;
+    int4 child;
+    int4 pad;
+};
+struct alignas(64) FTri { float4 v0; float4 e1; float4 e2; float4 bx; };  // v0.w = original index (bits); box = (e1.w, e2.w, bx.x) .. (bx.y, bx.z, bx.w)
+struct alignas(16) FNrm { float4 a, b, c; };                            // n0.xyz n1.x | n1.yz n2.xy | n2.z
+struct alignas(64) FInst { float4 r0, r1, r2; int32_t root, object, pad0, pad1; };
+struct alignas(32) FShade { float4 r0, r1, r2; float4 albedo, specular, emission; };
+
+constexpr int32_t kEmptyChild = (int32_t)0x80000001;
+constexpr int32_t kSentinel = (int32_t)0x80000000;   // "leave the instance" marker on the stack
+
+struct FastScene {
+    const WNode* tlasNodes;
+    const WNode* blasNodes;
+    const FInst* inst;
+    const FShade* shade;
+    const FTri* tris;
+    const FNrm* nrms;
+    const int32_t* superTiles;   // ids of the 32x32 pixel tiles this launch owns
+    int32_t nSuperTiles;
+    int32_t tlasRoot;            // index of the TLAS root in tlasNodes
+    int32_t* overflow;           // spill area for stacks deeper than the LDS part
+    int32_t overflowStride;      // lanes in the grid
+};
+
+template <typename T>
+struct DBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t count) {
+        if (p && count <= n) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc((void**)&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t put(const std::vector<T>& v, hipStream_t s) {
+        hipError_t e = ensure(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+// Host-side owner of the GPU layout.
+struct FastSceneHost {
+    DBuf<WNode> tlasNodes, blasNodes;
+    DBuf<FInst> inst;
+    DBuf<FShade> shade;
+    DBuf<FTri> tris;
+    DBuf<FNrm> nrms;
+    DBuf<int32_t> superTiles;
+    DBuf<int32_t> overflow;
+    std::vector<int32_t> blasRoot;     // wide-node index of each BLAS root
+    std::vector<WNode> hTlas;          // staging kept alive until the copy is done
+    std::vector<FInst> hInst;
+    std::vector<FShade> hShade;
+    std::vector<int32_t> hSuper;
+    int nInst = 0;
+
+    void release() {
+        tlasNodes.release(); blasNodes.release(); inst.release(); shade.release(); tris.release(); nrms.release();
+        superTiles.release(); overflow.release();
+    }
+
+    static void setChildBox(WNode& w, int slot, const rtamd_node& n, int i) {
+        (&w.lx.x)[slot] = n.Lx[i]; (&w.hx.x)[slot] = n.Hx[i];
+        (&w.ly.x)[slot] = n.Ly[i]; (&w.hy.x)[slot] = n.Hy[i];
+        (&w.lz.x)[slot] = n.Lz[i]; (&w.hz.x)[slot] = n.Hz[i];
+    }
+    static void setEmptyBox(WNode& w, int slot) {
+        (&w.lx.x)[slot] = (&w.ly.x)[slot] = (&w.lz.x)[slot] = 3.402823466e+38f;
+        (&w.hx.x)[slot] = (&w.hy.x)[slot] = (&w.hz.x)[slot] = -3.402823466e+38f;
+    }
+
+    // Re-pack every BLAS.  Inputs were validated by the caller (indices in range, every
+    // node reachable at most once).
+    hipError_t buildBottom(const int32_t* blasOffsets, const rtamd_node* blas, const int32_t* nodeCount,
+                           const int32_t* vtxOffsets, const rtamd_vertex* verts, const int32_t* triOffsets,
+                           const rtamd_int3* tris_, const int32_t* triCount, int nBlas, hipStream_t stream,
+                           std::string& err) {
+        std::vector<WNode> wn;
+        std::vector<FTri> ft;
+        std::vector<FNrm> fn;
+        blasRoot.assign(nBlas, 0);
+        for (int b = 0; b < nBlas; b++) {
+            const rtamd_node* nodes = blas + blasOffsets[b];
+            int nn = nodeCount[b];
+            const rtamd_int3* tri = tris_ + triOffsets[b];
+            const rtamd_vertex* vtx = verts + vtxOffsets[b];
+            size_t triBase = ft.size();
+            // pass 1: the reference's visiting order (children pushed 0..3, popped last first;
+            // leaf slots 0..3) gives every triangle its rank and every internal node its index
+            std::vector<int32_t> leafStart(nn, 0), leafCnt(nn, 0), wideIndex(nn, -1);
+            std::vector<int32_t> order;          // reference node indices of internal nodes, in visiting order
+            std::vector<int32_t> st;
+            st.push_back(1);
+            while (!st.empty()) {
+                int ni = st.back();
+                st.pop_back();
+                const rtamd_node& n = nodes[ni];
+                if (n.Flags == 0) {
+                    wideIndex[ni] = (int32_t)(wn.size() + order.size());
+                    order.push_back(ni);
+                    for (int i = 0; i < 4; i++) if (n.Data[i] != 0) st.push_back(n.Data[i]);
+                } else {
+                    leafStart[ni] = (int32_t)(ft.size() - triBase);
+                    for (int i = 0; i < 4; i++) {
+                        int t = n.Data[i];
+                        if (t == -1) continue;
+                        const float* p0 = vtx[tri[t].x].position;
+                        const float* p1 = vtx[tri[t].y].position;
+                        const float* p2 = vtx[tri[t].z].position;
+                        FTri f;
+                        f.v0 = make_float4(p0[0], p0[1], p0[2], 0.f);
+                        std::memcpy(&f.v0.w, &t, 4);
+                        // e1 = v1 - v0, e2 = v2 - v0: the same binary32 subtractions Trisection does (:201-202)
+                        f.e1 = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], n.Lx[i]);
+                        f.e2 = make_float4(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], n.Ly[i]);
+                        f.bx = make_float4(n.Lz[i], n.Hx[i], n.Hy[i], n.Hz[i]);
+                        ft.push_back(f);
+                        const float* n0 = vtx[tri[t].x].normal;
+                        const float* n1 = vtx[tri[t].y].normal;
+                        const float* n2 = vtx[tri[t].z].normal;
+                        FNrm g;
+                        g.a = make_float4(n0[0], n0[1], n0[2], n1[0]);
+                        g.b = make_float4(n1[1], n1[2], n2[0], n2[1]);
+                        g.c = make_float4(n2[2], 0.f, 0.f, 0.f);
+                        fn.push_back(g);
+                        leafCnt[ni]++;
+                    }
+                }
+            }
+            if (ft.size() >= (1u << 28)) { err = "too many triangles for the leaf encoding"; return hipSuccess; }
+            auto leafCode = [&](int ni) -> int32_t {
+                if (leafCnt[ni] == 0) return kEmptyChild;
+                uint32_t start = (uint32_t)(triBase + leafStart[ni]);
+                return ~(int32_t)((start << 2) | (uint32_t)(leafCnt[ni] - 1));
+            };
+            if (nodes[1].Flags != 0) {
+                // a tree whose root is itself a leaf node: wrap it so the kernel always starts at a node
+                WNode w;
+                std::memset(&w, 0, sizeof(w));
+                for (int s = 0; s < 4; s++) setEmptyBox(w, s);
+                int32_t ch[4] = {kEmptyChild, kEmptyChild, kEmptyChild, kEmptyChild};
+                const rtamd_node& n = nodes[1];
+                float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+                for (int i = 0; i < 4; i++) {
+                    if (n.Data[i] == -1) continue;
+                    lo[0] = std::fmin(lo[0], n.Lx[i]); lo[1] = std::fmin(lo[1], n.Ly[i]); lo[2] = std::fmin(lo[2], n.Lz[i]);
+                    hi[0] = std::fmax(hi[0], n.Hx[i]); hi[1] = std::fmax(hi[1], n.Hy[i]); hi[2] = std::fmax(hi[2], n.Hz[i]);
+                }
+                ch[0] = leafCode(1);
+                w.lx.x = lo[0]; w.ly.x = lo[1]; w.lz.x = lo[2]; w.hx.x = hi[0]; w.hy.x = hi[1]; w.hz.x = hi[2];
+                w.child = make_int4(ch[0], ch[1], ch[2], ch[3]);
+                blasRoot[b] = (int32_t)wn.size();
+                wn.push_back(w);
+                continue;
+            }
+            blasRoot[b] = wideIndex[1];
+            // pass 2: emit the internal nodes in the same order
+            for (int ni : order) {
+                const rtamd_node& n = nodes[ni];
+                WNode w;
+                std::memset(&w, 0, sizeof(w));
+                int32_t ch[4];
+                for (int i = 0; i < 4; i++) {
+                    int c = n.Data[i];
+                    if (c == 0) { ch[i] = kEmptyChild; setEmptyBox(w, i); continue; }
+                    setChildBox(w, i, n, i);
+                    ch[i] = nodes[c].Flags == 0 ? wideIndex[c] : leafCode(c);
+                    if (ch[i] == kEmptyChild) setEmptyBox(w, i);
+                }
+                w.child = make_int4(ch[0], ch[1], ch[2], ch[3]);
+                wn.push_back(w);
+            }
+        }
+        hipError_t e;
+        if ((e = blasNodes.put(wn, stream)) != hipSuccess) return e;
+        if ((e = tris.put(ft, stream)) != hipSuccess) return e;
+        if ((e = nrms.put(fn, stream)) != hipSuccess) return e;
+        return hipStreamSynchronize(stream);   // the staging vectors die with this scope
+    }
+
+    // Re-pack the TLAS (node for node) and the per-object data, instances in visiting order.
+    hipError_t buildTop(const rtamd_node* tlas, int nTlas, const rtamd_object_property* objects, int nObjects,
+                        hipStream_t stream, std::string& err) {
+        (void)nObjects;
+        hTlas.clear(); hInst.clear(); hShade.clear();
+        std::vector<int32_t> wideIndex(nTlas, -1), order, st;
+        st.push_back(1);
+        while (!st.empty()) {
+            int ni = st.back();
+            st.pop_back();
+            wideIndex[ni] = (int32_t)order.size();
+            order.push_back(ni);
+            const rtamd_node& n = tlas[ni];
+            if (n.Flags == 0)
+                for (int i = 0; i < 4; i++) if (n.Data[i] != 0) st.push_back(n.Data[i]);
+        }
+        for (int ni : order) {
+            const rtamd_node& n = tlas[ni];
+            WNode w;
+            std::memset(&w, 0, sizeof(w));
+            int32_t ch[4];
+            for (int i = 0; i < 4; i++) {
+                int d = n.Data[i];
+                bool valid = n.Flags == 0 ? d != 0 : d != -1;
+                if (!valid) { ch[i] = kEmptyChild; setEmptyBox(w, i); continue; }
+                setChildBox(w, i, n, i);
+                if (n.Flags == 0) { ch[i] = wideIndex[d]; continue; }
+                const rtamd_object_property& o = objects[d];
+                int rank = (int)hInst.size();
+                FInst fi;
+                const float* m = o.WorldToLocal;
+                fi.r0 = make_float4(m[0], m[4], m[8], m[12]);
+                fi.r1 = make_float4(m[1], m[5], m[9], m[13]);
+                fi.r2 = make_float4(m[2], m[6], m[10], m[14]);
+                fi.root = blasRoot[o.BLASIndex]; fi.object = d; fi.pad0 = fi.pad1 = 0;
+                hInst.push_back(fi);
+                FShade fs;
+                const float* l = o.LocalToWorld;
+                fs.r0 = make_float4(l[0], l[4], l[8], l[12]);
+                fs.r1 = make_float4(l[1], l[5], l[9], l[13]);
+                fs.r2 = make_float4(l[2], l[6], l[10], l[14]);
+                fs.albedo = make_float4(o.albedo[0], o.albedo[1], o.albedo[2], o.albedo[3]);
+                fs.specular = make_float4(o.specular[0], o.specular[1], o.specular[2], o.specular[3]);
+                fs.emission = make_float4(o.emission[0], o.emission[1], o.emission[2], o.emission[3]);
+                hShade.push_back(fs);
+                ch[i] = ~rank;
+            }
+            w.child = make_int4(ch[0], ch[1], ch[2], ch[3]);
+            hTlas.push_back(w);
+        }
+        if (hInst.empty()) { err = "TLAS references no object"; return hipSuccess; }
+        nInst = (int)hInst.size();
+        hipError_t e;
+        if ((e = tlasNodes.put(hTlas, stream)) != hipSuccess) return e;
+        if ((e = inst.put(hInst, stream)) != hipSuccess) return e;
+        return shade.put(hShade, stream);
+    }
+};
+
+// ------------------------------------------------------------------ kernel ---
+
+constexpr int kBlockThreads = 256;
+constexpr int kLdsStack = 32;        // stack entries per lane held in LDS
+constexpr int kMaxStack = 256;       // total, as the reference's BLAS stack (.compute:93)
+constexpr int kModeRef = 0, kModePt = 1, kModePrimary = 2;
+
+struct FastHit {
+    float t, u, v;
+    int32_t inst, tri;   // instance rank, absolute triangle slot
+};
+
+// mul(M, float4(v,1)).xyz and mul(M, float4(v,0)).xyz for a matrix stored as three rows.
+__device__ __forceinline__ V3 rowsPoint(float4 r0, float4 r1, float4 r2, V3 v) {
+    return v3(((r0.x * v.x + r0.y * v.y) + r0.z * v.z) + r0.w,
+              ((r1.x * v.x + r1.y * v.y) + r1.z * v.z) + r1.w,
+              ((r2.x * v.x + r2.y * v.y) + r2.z * v.z) + r2.w);
+}
+__device__ __forceinline__ V3 rowsDir(float4 r0, float4 r1, float4 r2, V3 v) {
+    return v3((r0.x * v.x + r0.y * v.y) + r0.z * v.z,
+              (r1.x * v.x + r1.y * v.y) + r1.z * v.z,
+              (r2.x * v.x + r2.y * v.y) + r2.z * v.z);
+}
+
+// One child of the four-box test (.compute:233-263): entry distance, or +inf if missed.
+__device__ __forceinline__ float slabNear(float lo_x, float hi_x, float lo_y, float hi_y, float lo_z, float hi_z,
+                                          const Ray& r, float maxFraction) {
+    float nearXt = (lo_x - r.origin.x) * r.invDir.x, farXt = (hi_x - r.origin.x) * r.invDir.x;
+    float nearYt = (lo_y - r.origin.y) * r.invDir.y, farYt = (hi_y - r.origin.y) * r.invDir.y;
+    float nearZt = (lo_z - r.origin.z) * r.invDir.z, farZt = (hi_z - r.origin.z) * r.invDir.z;
+    float nearX = fmin_(nearXt, farXt), farX = fmax_(nearXt, farXt);
+    float nearY = fmin_(nearYt, farYt), farY = fmax_(nearYt, farYt);
+    float nearZ = fmin_(nearZt, farZt), farZ = fmax_(nearZt, farZt);
+    float nearMax = fmax_(fmax_(fmax_(nearX, nearY), nearZ), 0.0f);
+    float farMin = fmin_(fmin_(fmin_(farX, farY), farZ), maxFraction);
+    return nearMax <= farMin ? nearMax : RT_INF;
+}
+__device__ __forceinline__ bool slabHit(float lo_x, float hi_x, float lo_y, float hi_y, float lo_z, float hi_z,
+                                        const Ray& r, float maxFraction) {
+    float nearXt = (lo_x - r.origin.x) * r.invDir.x, farXt = (hi_x - r.origin.x) * r.invDir.x;
+    float nearYt = (lo_y - r.origin.y) * r.invDir.y, farYt = (hi_y - r.origin.y) * r.invDir.y;
+    float nearZt = (lo_z - r.origin.z) * r.invDir.z, farZt = (hi_z - r.origin.z) * r.invDir.z;
+    float nearX = fmin_(nearXt, farXt), farX = fmax_(nearXt, farXt);
+    float nearY = fmin_(nearYt, farYt), farY = fmax_(nearYt, farYt);
+    float nearZ = fmin_(nearZt, farZt), farZ = fmax_(nearZt, farZt);
+    float nearMax = fmax_(fmax_(fmax_(nearX, nearY), nearZ), 0.0f);
+    float farMin = fmin_(fmin_(fmin_(farX, farY), farZ), maxFraction);
+    return nearMax <= farMin;
+}
+
+__device__ __forceinline__ void cswap(float& da, int32_t& ca, float& db, int32_t& cb) {
+    bool sw = db < da;
+    float td = sw ? db : da; float tb = sw ? da : db;
+    int32_t tc = sw ? cb : ca; int32_t te = sw ? ca : cb;
+    da = td; db = tb; ca = tc; cb = te;
+}
+
+struct Surf { V3 position, normal, albedo, specular, emission; int32_t object, triangle; };
+
+// Position, shading normal and material of the closest hit (.compute:329-339).
+__device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world, const FastHit& h) {
+    const FInst fi = sc.inst[h.inst];
+    const FShade fs = sc.shade[h.inst];
+    Ray local = makeRay(rowsPoint(fi.r0, fi.r1, fi.r2, world.origin), rowsDir(fi.r0, fi.r1, fi.r2, world.direction));
+    Surf s;
+    s.position = rowsPoint(fs.r0, fs.r1, fs.r2, local.origin + h.t * local.direction);
+    const FNrm g = sc.nrms[h.tri];
+    V3 n0 = v3(g.a.x, g.a.y, g.a.z), n1 = v3(g.a.w, g.b.x, g.b.y), n2 = v3(g.b.z, g.b.w, g.c.x);
+    float w = 1 - h.u - h.v;
+    V3 nl = ((h.u * n1) + (h.v * n2)) + (w * n0);
+    s.normal = normalize(rowsDir(fs.r0, fs.r1, fs.r2, nl));
+    s.albedo = v3(fs.albedo.x, fs.albedo.y, fs.albedo.z);
+    s.specular = v3(fs.specular.x, fs.specular.y, fs.specular.z);
+    s.emission = v3(fs.emission.x, fs.emission.y, fs.emission.z);
+    s.object = fi.object;
+    s.triangle = __float_as_int(sc.tris[h.tri].v0.w);
+    return s;
+}
+
+// Persistent kernel.  Each lane owns one pixel at a time and walks all of its samples
+// and bounces, so a pixel's sum is formed in a fixed order.  Lanes whose ray has
+// finished wait until enough of the wave is waiting, then shade / start new rays /
+// fetch new pixels together (ballot-driven regrouping); the wave draws pixels from one
+// global counter in 8x8 tiles.
+template <int MODE>
+__global__ __launch_bounds__(kBlockThreads) void kFast(FastScene sc, Sky sky, RenderArgs a, int refillBelow) {
+    __shared__ int32_t ldsStack[kLdsStack][kBlockThreads];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int gl = blockIdx.x * kBlockThreads + tid;
+    const unsigned long long totalWork = (unsigned long long)sc.nSuperTiles * 1024ull;
+
+    // pixel state
+    bool pixelActive = false, noMoreWork = false;
+    int px = 0, py = 0;
+    int sample = 0;
+    V3 sum = v3(0, 0, 0);
+    // path state
+    bool pathActive = false;
+    uint32_t key = 0;
+    int bounce = 0;
+    V3 energy = v3(1, 1, 1), L = v3(0, 0, 0);
+    // traversal state
+    bool trav = false;
+    Ray world = makeRay(v3(0, 0, 0), v3(0, 0, 1));
+    Ray cur = world;
+    FastHit best;
+    best.t = RT_INF; best.u = best.v = 0; best.inst = -1; best.tri = -1;
+    int32_t node = 0;
+    int sp = 0;
+    bool inBlas = false;
+    int32_t curInst = -1;
+    uint32_t rays = 0;
+    bool overflowed = false;
+
+    // The LDS part and the spill part are accessed by separate statements on purpose: an
+    // if/else over the two address spaces gets merged into one flat access by the optimiser.
+#define RT_PUSH(v)                                                                                      \
+    do {                                                                                                \
+        const int32_t pv_ = (v);                                                                        \
+        if (sp < kLdsStack) ldsStack[sp][tid] = pv_;                                                    \
+        if (sp >= kLdsStack && sp < kMaxStack) sc.overflow[(size_t)(sp - kLdsStack) * sc.overflowStride + gl] = pv_; \
+        if (sp >= kMaxStack) overflowed = true; else sp++;                                              \
+    } while (0)
+#define RT_POP(dst)                                                                                     \
+    do {                                                                                                \
+        sp--;                                                                                           \
+        dst = ldsStack[sp < kLdsStack ? sp : kLdsStack - 1][tid];                                       \
+        if (sp >= kLdsStack) dst = sc.overflow[(size_t)(sp - kLdsStack) * sc.overflowStride + gl];      \
+    } while (0)
+
+    for (;;) {
+        // ------------------------------------------------ phase A: lanes without a ray
+        if (!trav) {
+            bool haveRay = false;
+            Ray next = world;
+            if (pathActive) {
+                // the segment just traversed
+                if (best.t < RT_INF) {
+                    Surf s = resolveHit(sc, world, best);
+                    if (MODE == kModePt) {
+                        L = L + energy * s.emission;
+                        V3 dir;
+                        if (bounce < a.maxBounces && scatter(s.albedo, s.specular, s.normal, world.direction, key, (uint32_t)bounce, energy, dir)) {
+                            next = makeRay(s.position + s.normal * 0.001f, dir);
+                            bounce++;
+                            haveRay = true;
+                        }
+                    } else {
+                        size_t pix = (size_t)py * a.width + px;
+                        if (bounce == 0) {
+                            if (a.outIds) { a.outIds[2 * pix] = s.object; a.outIds[2 * pix + 1] = s.triangle; }
+                            if (a.outT) a.outT[pix] = best.t;
+                            if (MODE == kModeRef) {
+                                // Trace: mirror ray from the hit position, no offset (.compute:419)
+                                next = makeRay(s.position, reflect(world.direction, s.normal));
+                                bounce = 1;
+                                haveRay = true;
+                            }
+                        } else {
+                            L = v3(0, 0, 0) + v3(1, 1, 1) * s.emission;      // Shade, hit branch (:400)
+                            if (a.outRgba) a.outRgba[pix] = make_float4(L.x, L.y, L.z, 1.0f);
+                        }
+                    }
+                } else {
+                    if (MODE == kModePt) {
+                        L = L + energy * shadeMiss(sky, world.direction);
+                    } else {
+                        size_t pix = (size_t)py * a.width + px;
+                        if (bounce == 0) {
+                            if (a.outIds) { a.outIds[2 * pix] = -1; a.outIds[2 * pix + 1] = -1; }
+                            if (a.outT) a.outT[pix] = RT_INF;
+                            if (MODE == kModeRef && a.outRgba) a.outRgba[pix] = make_float4(0, 0, 0, 0);   // .compute:427
+                        } else {
+                            L = v3(0, 0, 0) + v3(1, 1, 1) * shadeMiss(sky, world.direction);
+                            if (a.outRgba) a.outRgba[pix] = make_float4(L.x, L.y, L.z, 1.0f);
+                        }
+                    }
+                }
+                if (!haveRay) {
+                    pathActive = false;
+                    if (MODE == kModePt) { sum = sum + L; sample++; }
+                    else sample = 1;
+                }
+            }
+            if (!haveRay && pixelActive && sample >= (MODE == kModePt ? a.spp : 1)) {
+                if (MODE == kModePt) writePathPixel(a, (size_t)py * a.width + px, sum);
+                pixelActive = false;
+            }
+            // fetch pixels for lanes that have none: one atomic per wave and round, shared by ballot
+            for (;;) {
+                bool need = !trav && !haveRay && !pixelActive && !noMoreWork;
+                unsigned long long m = __ballot(need);
+                if (m == 0ull) break;
+                int leader = __ffsll((long long)m) - 1;
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(a.rayCount + 1, (unsigned long long)__popcll(m));
+                base = __shfl(base, leader, 64);
+                if (need) {
+                    unsigned long long w = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+                    if (w >= totalWork) noMoreWork = true;
+                    else {
+                        int st = sc.superTiles[(int)(w >> 10)];
+                        int within = (int)(w & 1023ull);
+                        int tilesX = (a.width + 31) / 32;
+                        int sx = st % tilesX, sy = st / tilesX;
+                        int t8 = within >> 6, p8 = within & 63;
+                        int x = sx * 32 + (t8 & 3) * 8 + (p8 & 7);
+                        int y = sy * 32 + (t8 >> 2) * 8 + (p8 >> 3);
+                        if (x < a.width && y < a.height && x >= a.tileX && y >= a.tileY && x < a.tileX + a.tileW && y < a.tileY + a.tileH) {
+                            px = x; py = y; pixelActive = true; sample = 0; sum = v3(0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if (!haveRay && pixelActive) {
+                // start the next sample of this pixel
+                float jx = a.cb.PixelOffset[0], jy = a.cb.PixelOffset[1];
+                if (MODE == kModePt) {
+                    key = rngKey(a.seedHi, a.seedLo, (uint32_t)((size_t)py * a.width + px), (uint32_t)(a.sampleOffset + sample));
+                    if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
+                }
+                next = cameraRay(a.cb, pixelToNdc(px, jx, a.width), pixelToNdc(py, jy, a.height));
+                energy = v3(1, 1, 1); L = v3(0, 0, 0); bounce = 0;
+                pathActive = true;
+                haveRay = true;
+            }
+            if (haveRay) {
+                world = next; cur = next;
+                best.t = RT_INF; best.inst = -1; best.tri = -1;
+                node = sc.tlasRoot; sp = 0; inBlas = false;
+                trav = true;
+                rays++;
+            }
+        }
+        // ------------------------------------------------ phase B: traversal
+        unsigned long long active = __ballot(trav);
+        if (active == 0ull) {
+            // nobody got a ray: every lane is out of work
+            break;
+        }
+        for (;;) {
+            if (trav) {
+                if (node >= 0) {
+                    const WNode* nb = inBlas ? sc.blasNodes : sc.tlasNodes;
+                    const float4* np = reinterpret_cast<const float4*>(nb + node);
+                    float4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5];
+                    int4 ch = reinterpret_cast<const int4*>(np)[6];
+                    float d0 = slabNear(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, cur, best.t);
+                    float d1 = slabNear(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, cur, best.t);
+                    float d2 = slabNear(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, cur, best.t);
+                    float d3 = slabNear(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, cur, best.t);
+                    int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+                    if (c0 == kEmptyChild) d0 = RT_INF;
+                    if (c1 == kEmptyChild) d1 = RT_INF;
+                    if (c2 == kEmptyChild) d2 = RT_INF;
+                    if (c3 == kEmptyChild) d3 = RT_INF;
+                    int nh = (d0 < RT_INF) + (d1 < RT_INF) + (d2 < RT_INF) + (d3 < RT_INF);
+                    // sort by entry distance (misses = +inf go last)
+                    cswap(d0, c0, d1, c1); cswap(d2, c2, d3, c3); cswap(d0, c0, d2, c2); cswap(d1, c1, d3, c3); cswap(d1, c1, d2, c2);
+                    if (nh > 3) RT_PUSH(c3);
+                    if (nh > 2) RT_PUSH(c2);
+                    if (nh > 1) RT_PUSH(c1);
+                    node = nh > 0 ? c0 : kSentinel + 2;   // "+2" = pop marker
+                } else if (!inBlas) {
+                    // enter an instance (.compute:279-287)
+                    int rank = ~node;
+                    const FInst fi = sc.inst[rank];
+                    cur = makeRay(rowsPoint(fi.r0, fi.r1, fi.r2, world.origin), rowsDir(fi.r0, fi.r1, fi.r2, world.direction));
+                    RT_PUSH(kSentinel);
+                    node = fi.root;
+                    inBlas = true;
+                    curInst = rank;
+                } else {
+                    uint32_t code = (uint32_t)~node;
+                    uint32_t start = code >> 2;
+                    int cnt = (int)(code & 3u) + 1;
+                    const float tEntry = best.t;   // the reference masks all four slots before testing any (:298)
+                    for (int k = 0; k < cnt; k++) {
+                        const FTri tr = sc.tris[start + k];
+                        if (!slabHit(tr.e1.w, tr.bx.y, tr.e2.w, tr.bx.z, tr.bx.x, tr.bx.w, cur, tEntry)) continue;
+                        float t, u, v;
+                        if (trisect(cur.origin, cur.direction, v3(tr.v0.x, tr.v0.y, tr.v0.z), v3(tr.e1.x, tr.e1.y, tr.e1.z),
+                                    v3(tr.e2.x, tr.e2.y, tr.e2.z), t, u, v)) {
+                            int32_t ti = (int32_t)(start + k);
+                            bool closer = t < best.t;
+                            bool tie = t == best.t && (curInst < best.inst || (curInst == best.inst && ti < best.tri));
+                            if (closer || tie) { best.t = t; best.u = u; best.v = v; best.inst = curInst; best.tri = ti; }
+                        }
+                    }
+                    node = kSentinel + 2;
+                }
+                // pop
+                while (node == kSentinel + 2) {
+                    if (sp == 0) { trav = false; break; }
+                    RT_POP(node);
+                    if (node == kSentinel) { cur = world; inBlas = false; node = kSentinel + 2; }
+                }
+            }
+            unsigned long long m = __ballot(trav);
+            if (m == 0ull) break;
+            if (__popcll(m) < refillBelow) {
+                // leave only if some waiting lane can actually be given a new ray
+                bool canRefill = !trav && !(noMoreWork && !pixelActive && !pathActive);
+                if (__ballot(canRefill) != 0ull) break;
+            }
+        }
+    }
+#undef RT_PUSH
+#undef RT_POP
+    if (overflowed) atomicOr(a.errorFlag, 1);
+    unsigned long long r = rays;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
+    if (lane == 0 && r) atomicAdd(a.rayCount, r);
+}
+
+inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs& a, hipStream_t stream) {
+    // 32x32 tiles intersecting the rectangle and owned by this shard
+    int tilesX = (a.width + 31) / 32;
+    fs.hSuper.clear();
+    int sx0 = a.tileX / 32, sx1 = (a.tileX + a.tileW - 1) / 32, sy0 = a.tileY / 32, sy1 = (a.tileY + a.tileH - 1) / 32;
+    for (int sy = sy0; sy <= sy1; sy++)
+        for (int sx = sx0; sx <= sx1; sx++) {
+            int id = sy * tilesX + sx;
+            if (a.shardCount > 1 && id % a.shardCount != a.shardRank) continue;
+            fs.hSuper.push_back(id);
+        }
+    if (fs.hSuper.empty()) return hipSuccess;
+    hipError_t e = fs.superTiles.put(fs.hSuper, stream);
+    if (e != hipSuccess) return e;
+
+    static int numCU = 0;
+    if (!numCU) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+        numCU = prop.multiProcessorCount;
+    }
+    int blocksPerCU = 4;
+    if (const char* s = getenv("RTAMD_BLOCKS_PER_CU")) { int v = atoi(s); if (v > 0 && v <= 8) blocksPerCU = v; }
+    int refillBelow = 40;
+    if (const char* s = getenv("RTAMD_REFILL_BELOW")) { int v = atoi(s); if (v >= 1 && v <= 64) refillBelow = v; }
+    long long wavesNeeded = ((long long)fs.hSuper.size() * 1024 + 63) / 64;
+    long long blocksNeeded = (wavesNeeded + 3) / 4;
+    int grid = numCU * blocksPerCU;
+    if (blocksNeeded < grid) grid = (int)blocksNeeded;
+    if (grid < 1) grid = 1;
+    size_t lanes = (size_t)grid * kBlockThreads;
+    if ((e = fs.overflow.ensure(lanes * (size_t)(kMaxStack - kLdsStack))) != hipSuccess) return e;
+
+    FastScene sc;
+    sc.tlasNodes = fs.tlasNodes.p; sc.blasNodes = fs.blasNodes.p; sc.inst = fs.inst.p; sc.shade = fs.shade.p;
+    sc.tris = fs.tris.p; sc.nrms = fs.nrms.p; sc.superTiles = fs.superTiles.p; sc.nSuperTiles = (int)fs.hSuper.size();
+    sc.tlasRoot = 0; sc.overflow = fs.overflow.p; sc.overflowStride = (int)lanes;
+
+    if (a.mode == RTAMD_MODE_PT && (a.outIds || a.outT)) {
+        // identity of the un-jittered primary hit: a separate, uncounted pass
+        RenderArgs ids = a;
+        ids.outRgba = nullptr; ids.accum = nullptr; ids.spp = 1;
+        hipLaunchKernelGGL(kFast<kModePrimary>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, ids, refillBelow);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        // the work-queue head and ray counter are shared: reset them between the passes
+        if ((e = hipMemsetAsync(a.rayCount, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+    }
+    if (a.mode == RTAMD_MODE_PT)
+        hipLaunchKernelGGL(kFast<kModePt>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, refillBelow);
+    else
+        hipLaunchKernelGGL(kFast<kModeRef>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, refillBelow);
+    return hipGetLastError();
+}
+
+}  // namespace rt

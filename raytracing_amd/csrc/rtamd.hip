@@ -1,0 +1,473 @@
+// librtamd: host side of the C ABI declared in include/rtamd.h — context, scene upload
+// and validation, re-packing for the GPU, kernel launches, timing.
+//
+// Boundary replaced: CustomRenderPass.Execute (Assets/Script/RenderPass/RayTracingPass.cs:
+// 62-109) and the ComputeBuffer plumbing of BuildAccelerateStructureSystem.OnUpdate
+// (Assets/Script/RayTracing/System/BuildAccelerateStructureSystem.cs:119-158).
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernel_faithful.h"
+#include "kernel_fast.h"
+#include "rtamd.h"
+
+static_assert(sizeof(rtamd_node) == 116, "Node stride");
+static_assert(sizeof(rtamd_vertex) == 24, "Vertex stride");
+static_assert(sizeof(rtamd_int3) == 12, "int3 stride");
+static_assert(sizeof(rtamd_object_property) == 180, "PerObjectProperty stride");
+static_assert(sizeof(rtamd_frame_cbuffer) == 144, "FrameCBuffer size");
+
+namespace {
+
+thread_local std::string g_createError;
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc((void**)&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) n = count; else p = nullptr;
+        return e;
+    }
+    hipError_t upload(const T* src, size_t count, hipStream_t s) {
+        hipError_t e = alloc(count);
+        if (e != hipSuccess || !count) return e;
+        return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace
+
+struct rtamd_ctx {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    std::string error;
+
+    // reference-layout copies (used by the reference-order kernel)
+    DevBuf<rtamd_node> tlas, blas;
+    DevBuf<int32_t> blasOffsets, vtxOffsets, triOffsets;
+    DevBuf<rtamd_vertex> verts;
+    DevBuf<rtamd_int3> tris;
+    DevBuf<rtamd_object_property> objects;
+    int nTlas = 0, nBlasNodes = 0, nVerts = 0, nTris = 0, nBlas = 0, nObjects = 0;
+    bool haveScene = false;
+
+    // host copies of what the re-pack needs again on an object refresh
+    std::vector<int32_t> hBlasOffsets, hTriOffsets, hVtxOffsets;
+    std::vector<int32_t> hBlasNodeCount, hBlasTriCount, hBlasVertCount;
+
+    // GPU layout (production kernel)
+    rt::FastSceneHost fast;
+
+    DevBuf<float4> sky;
+    int skyW = 0, skyH = 0;
+
+    DevBuf<float4> accum;
+    int accumW = 0, accumH = 0;
+
+    DevBuf<float4> outRgba;      // staging when the caller passes host pointers
+    DevBuf<int32_t> outIds;
+    DevBuf<float> outT;
+    DevBuf<rt::DevCounters> counters;     // [0] counters
+    DevBuf<unsigned long long> rayCount;  // [0] rays, [1] work-queue head
+    DevBuf<int32_t> errorFlag;
+
+    float lastKernelMs = 0.f;
+    uint64_t lastRays = 0;
+};
+
+namespace {
+
+int fail(rtamd_ctx* c, int code, const std::string& msg) {
+    if (c) c->error = msg; else g_createError = msg;
+    return code;
+}
+int failHip(rtamd_ctx* c, hipError_t e, const char* what) {
+    return fail(c, e == hipErrorOutOfMemory ? RTAMD_ERR_OUT_OF_MEMORY : RTAMD_ERR_HIP,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(c, expr)                                   \
+    do {                                                   \
+        hipError_t _e = (expr);                            \
+        if (_e != hipSuccess) return failHip(c, _e, #expr); \
+    } while (0)
+
+bool isDevicePointer(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// Walk the nodes reachable from node 1 of one tree and check every index the kernels
+// will follow.  leafLimit = number of primitives (objects for the TLAS).
+int validateTree(rtamd_ctx* c, const rtamd_node* nodes, int nNodes, int leafLimit, const char* what) {
+    if (nNodes < 2) return fail(c, RTAMD_ERR_BAD_INDEX, std::string(what) + ": fewer than 2 nodes");
+    std::vector<uint8_t> seen((size_t)nNodes, 0);
+    std::vector<int> st;
+    st.push_back(1);
+    seen[1] = 1;
+    while (!st.empty()) {
+        int ni = st.back();
+        st.pop_back();
+        const rtamd_node& n = nodes[ni];
+        for (int i = 0; i < 4; i++) {
+            int d = n.Data[i];
+            if (n.Flags == 0) {
+                if (d == 0) continue;
+                if (d < 0 || d >= nNodes) return fail(c, RTAMD_ERR_BAD_INDEX, std::string(what) + ": child index out of range");
+                if (seen[d]) return fail(c, RTAMD_ERR_BAD_INDEX, std::string(what) + ": node reachable twice");
+                seen[d] = 1;
+                st.push_back(d);
+            } else {
+                if (d == -1) continue;
+                if (d < 0 || d >= leafLimit) return fail(c, RTAMD_ERR_BAD_INDEX, std::string(what) + ": leaf index out of range");
+            }
+        }
+    }
+    return RTAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rtamd_version(void) { return "rtamd 0.1 gfx950"; }
+
+const char* rtamd_last_error_string(const rtamd_ctx* ctx) {
+    return ctx ? ctx->error.c_str() : g_createError.c_str();
+}
+
+int rtamd_ctx_create(int device_ordinal, rtamd_ctx** out_ctx) {
+    if (!out_ctx) return fail(nullptr, RTAMD_ERR_INVALID_ARG, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, RTAMD_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)");
+    }
+    if (device_ordinal < 0 || device_ordinal >= count) return fail(nullptr, RTAMD_ERR_INVALID_ARG, "device ordinal out of range");
+    rtamd_ctx* c = new (std::nothrow) rtamd_ctx();
+    if (!c) return fail(nullptr, RTAMD_ERR_OUT_OF_MEMORY, "host allocation failed");
+    c->device = device_ordinal;
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess ||
+        (e = c->counters.alloc(1)) != hipSuccess || (e = c->rayCount.alloc(2)) != hipSuccess || (e = c->errorFlag.alloc(1)) != hipSuccess) {
+        int rc = failHip(nullptr, e, "context creation");
+        rtamd_ctx_destroy(c);
+        return rc;
+    }
+    c->stream = c->ownStream;
+    *out_ctx = c;
+    return RTAMD_OK;
+}
+
+int rtamd_ctx_destroy(rtamd_ctx* c) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->tlas.release(); c->blas.release(); c->blasOffsets.release(); c->vtxOffsets.release(); c->triOffsets.release();
+    c->verts.release(); c->tris.release(); c->objects.release(); c->sky.release(); c->accum.release();
+    c->outRgba.release(); c->outIds.release(); c->outT.release(); c->counters.release(); c->rayCount.release();
+    c->errorFlag.release();
+    c->fast.release();
+    if (c->evStart) (void)hipEventDestroy(c->evStart);
+    if (c->evStop) (void)hipEventDestroy(c->evStop);
+    if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+    delete c;
+    return RTAMD_OK;
+}
+
+int rtamd_set_stream(rtamd_ctx* c, void* s) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    c->stream = s ? (hipStream_t)s : c->ownStream;
+    return RTAMD_OK;
+}
+
+static int uploadTlasAndObjects(rtamd_ctx* c, const rtamd_node* tlas, int nTlas, const rtamd_object_property* objects,
+                                int nObjects) {
+    int rc = validateTree(c, tlas, nTlas, nObjects, "TLAS");
+    if (rc) return rc;
+    for (int o = 0; o < nObjects; o++)
+        if (objects[o].BLASIndex < 0 || objects[o].BLASIndex >= c->nBlas)
+            return fail(c, RTAMD_ERR_BAD_INDEX, "object BLASIndex out of range");
+    HIP_TRY(c, c->tlas.upload(tlas, nTlas, c->stream));
+    HIP_TRY(c, c->objects.upload(objects, nObjects, c->stream));
+    c->nTlas = nTlas;
+    c->nObjects = nObjects;
+    std::string err;
+    hipError_t e = c->fast.buildTop(tlas, nTlas, objects, nObjects, c->stream, err);
+    if (e != hipSuccess) return failHip(c, e, "TLAS re-pack");
+    if (!err.empty()) return fail(c, RTAMD_ERR_BAD_INDEX, err);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTAMD_OK;
+}
+
+int rtamd_scene_upload(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas, const int32_t* blasOffsets,
+                       const rtamd_node* blas, int32_t nBlasNodes, const int32_t* vtxOffsets,
+                       const rtamd_vertex* verts, int32_t nVerts, const int32_t* triOffsets, const rtamd_int3* tris,
+                       int32_t nTris, int32_t nBlas, const rtamd_object_property* objects, int32_t nObjects) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!tlas || !blasOffsets || !blas || !vtxOffsets || !verts || !triOffsets || !tris || !objects)
+        return fail(c, RTAMD_ERR_INVALID_ARG, "NULL scene buffer");
+    if (nTlas < 2 || nBlasNodes < 2 || nVerts < 1 || nTris < 1 || nBlas < 1 || nObjects < 1)
+        return fail(c, RTAMD_ERR_INVALID_ARG, "empty scene buffer (the reference skips the dispatch when ObjectsCount == 0)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->haveScene = false;
+    // offsets: exclusive prefix sums, BuildAccelerateStructureSystem.cs:105-117
+    std::vector<int32_t> nodeCnt(nBlas), triCnt(nBlas), vertCnt(nBlas);
+    for (int b = 0; b < nBlas; b++) {
+        int no = blasOffsets[b], to = triOffsets[b], vo = vtxOffsets[b];
+        int ne = b + 1 < nBlas ? blasOffsets[b + 1] : nBlasNodes;
+        int te = b + 1 < nBlas ? triOffsets[b + 1] : nTris;
+        int ve = b + 1 < nBlas ? vtxOffsets[b + 1] : nVerts;
+        if (no < 0 || ne > nBlasNodes || ne - no < 2 || to < 0 || te > nTris || te <= to || vo < 0 || ve > nVerts || ve <= vo)
+            return fail(c, RTAMD_ERR_BAD_INDEX, "BLAS offsets are not increasing prefix sums inside the buffers");
+        nodeCnt[b] = ne - no; triCnt[b] = te - to; vertCnt[b] = ve - vo;
+        int rc = validateTree(c, blas + no, ne - no, te - to, "BLAS");
+        if (rc) return rc;
+        for (int t = to; t < te; t++) {
+            const rtamd_int3& tr = tris[t];
+            if (tr.x < 0 || tr.y < 0 || tr.z < 0 || tr.x >= ve - vo || tr.y >= ve - vo || tr.z >= ve - vo)
+                return fail(c, RTAMD_ERR_BAD_INDEX, "triangle vertex index out of range");
+        }
+    }
+    c->nBlas = nBlas;
+    c->hBlasOffsets.assign(blasOffsets, blasOffsets + nBlas);
+    c->hTriOffsets.assign(triOffsets, triOffsets + nBlas);
+    c->hVtxOffsets.assign(vtxOffsets, vtxOffsets + nBlas);
+    c->hBlasNodeCount = nodeCnt; c->hBlasTriCount = triCnt; c->hBlasVertCount = vertCnt;
+
+    HIP_TRY(c, c->blasOffsets.upload(blasOffsets, nBlas, c->stream));
+    HIP_TRY(c, c->vtxOffsets.upload(vtxOffsets, nBlas, c->stream));
+    HIP_TRY(c, c->triOffsets.upload(triOffsets, nBlas, c->stream));
+    HIP_TRY(c, c->blas.upload(blas, nBlasNodes, c->stream));
+    HIP_TRY(c, c->verts.upload(verts, nVerts, c->stream));
+    HIP_TRY(c, c->tris.upload(tris, nTris, c->stream));
+    c->nBlasNodes = nBlasNodes; c->nVerts = nVerts; c->nTris = nTris;
+
+    std::string err;
+    hipError_t e = c->fast.buildBottom(blasOffsets, blas, nodeCnt.data(), vtxOffsets, verts, triOffsets, tris,
+                                       triCnt.data(), nBlas, c->stream, err);
+    if (e != hipSuccess) return failHip(c, e, "BLAS re-pack");
+    if (!err.empty()) return fail(c, RTAMD_ERR_BAD_INDEX, err);
+
+    int rc = uploadTlasAndObjects(c, tlas, nTlas, objects, nObjects);
+    if (rc) return rc;
+    c->haveScene = true;
+    return RTAMD_OK;
+}
+
+int rtamd_scene_refresh_objects(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas,
+                                const rtamd_object_property* objects, int32_t nObjects) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->haveScene) return fail(c, RTAMD_ERR_NO_SCENE, "refresh before a scene upload");
+    if (!tlas || !objects || nTlas < 2) return fail(c, RTAMD_ERR_INVALID_ARG, "NULL / empty buffer");
+    if (nObjects != c->nObjects) return fail(c, RTAMD_ERR_INVALID_ARG, "object count differs from the uploaded scene");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->haveScene = false;
+    int rc = uploadTlasAndObjects(c, tlas, nTlas, objects, nObjects);
+    if (rc) return rc;
+    c->haveScene = true;
+    return RTAMD_OK;
+}
+
+int rtamd_sky_upload(rtamd_ctx* c, const float* rgba, int32_t w, int32_t h) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!rgba || w <= 0 || h <= 0) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->sky.release(); c->skyW = c->skyH = 0;
+        return RTAMD_OK;
+    }
+    HIP_TRY(c, c->sky.upload((const float4*)rgba, (size_t)w * h, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->skyW = w; c->skyH = h;
+    return RTAMD_OK;
+}
+
+int rtamd_accum_reset(rtamd_ctx* c) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->accum.p) HIP_TRY(c, hipMemsetAsync(c->accum.p, 0, c->accum.n * sizeof(float4), c->stream));
+    return RTAMD_OK;
+}
+
+int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_params* ext, int32_t width,
+                 int32_t height, float* out_rgba, int32_t* out_prim_id) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!frame) return fail(c, RTAMD_ERR_INVALID_ARG, "frame is NULL");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (1ll << 30)) return fail(c, RTAMD_ERR_INVALID_ARG, "bad image size");
+    if (!c->haveScene) return fail(c, RTAMD_ERR_NO_SCENE, "render before a scene upload");
+    rtamd_ext_params e;
+    std::memset(&e, 0, sizeof(e));
+    e.struct_size = sizeof(e); e.mode = RTAMD_MODE_REF; e.spp = 1;
+    if (ext) {
+        if (ext->struct_size != sizeof(rtamd_ext_params)) return fail(c, RTAMD_ERR_INVALID_ARG, "ext.struct_size mismatch");
+        e = *ext;
+    }
+    if (e.mode != RTAMD_MODE_REF && e.mode != RTAMD_MODE_PT) return fail(c, RTAMD_ERR_INVALID_ARG, "unknown mode");
+    if (e.mode == RTAMD_MODE_PT && (e.spp < 1 || e.max_bounces < 0 || e.sample_offset < 0))
+        return fail(c, RTAMD_ERR_INVALID_ARG, "PT mode needs spp >= 1, max_bounces >= 0, sample_offset >= 0");
+    if (e.shard_count > 1 && (e.shard_rank < 0 || e.shard_rank >= e.shard_count)) return fail(c, RTAMD_ERR_INVALID_ARG, "shard_rank out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t npix = (size_t)width * height;
+
+    rt::RenderArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.cb = *frame;
+    a.width = width; a.height = height;
+    a.mode = e.mode; a.spp = e.mode == RTAMD_MODE_PT ? e.spp : 1; a.maxBounces = e.max_bounces;
+    a.seedHi = (uint32_t)(e.seed >> 32); a.seedLo = (uint32_t)e.seed;
+    a.sampleOffset = e.sample_offset;
+    a.tileX = 0; a.tileY = 0; a.tileW = width; a.tileH = height;
+    bool partial = e.shard_count > 1;
+    if (e.tile_w > 0 && e.tile_h > 0) {
+        int x0 = e.tile_x < 0 ? 0 : e.tile_x, y0 = e.tile_y < 0 ? 0 : e.tile_y;
+        int x1 = e.tile_x + e.tile_w > width ? width : e.tile_x + e.tile_w;
+        int y1 = e.tile_y + e.tile_h > height ? height : e.tile_y + e.tile_h;
+        a.tileX = x0; a.tileY = y0; a.tileW = x1 > x0 ? x1 - x0 : 0; a.tileH = y1 > y0 ? y1 - y0 : 0;
+        partial = true;
+    }
+    a.shardRank = e.shard_rank; a.shardCount = e.shard_count;
+    a.flags = e.flags;
+    bool wantCounters = (e.flags & RTAMD_FLAG_COUNTERS) && e.out_counters;
+    bool faithful = (e.flags & RTAMD_FLAG_REFERENCE_ORDER) || wantCounters;
+
+    // outputs: device pointers are written in place, host pointers go through staging
+    bool rgbaDev = isDevicePointer(out_rgba), idsDev = isDevicePointer(out_prim_id), tDev = isDevicePointer(e.out_t);
+    if (out_rgba && !rgbaDev) {
+        HIP_TRY(c, c->outRgba.alloc(npix));
+        if (partial) HIP_TRY(c, hipMemcpyAsync(c->outRgba.p, out_rgba, npix * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    }
+    if (out_prim_id && !idsDev) {
+        HIP_TRY(c, c->outIds.alloc(npix * 2));
+        if (partial) HIP_TRY(c, hipMemcpyAsync(c->outIds.p, out_prim_id, npix * 2 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
+    if (e.out_t && !tDev) {
+        HIP_TRY(c, c->outT.alloc(npix));
+        if (partial) HIP_TRY(c, hipMemcpyAsync(c->outT.p, e.out_t, npix * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    a.outRgba = out_rgba ? (rgbaDev ? (float4*)out_rgba : c->outRgba.p) : nullptr;
+    a.outIds = out_prim_id ? (idsDev ? out_prim_id : c->outIds.p) : nullptr;
+    a.outT = e.out_t ? (tDev ? e.out_t : c->outT.p) : nullptr;
+    if (e.mode == RTAMD_MODE_PT && (e.flags & RTAMD_FLAG_ACCUMULATE)) {
+        if (c->accumW != width || c->accumH != height || !c->accum.p) {
+            HIP_TRY(c, c->accum.alloc(npix));
+            HIP_TRY(c, hipMemsetAsync(c->accum.p, 0, npix * sizeof(float4), c->stream));
+            c->accumW = width; c->accumH = height;
+        }
+        a.accum = c->accum.p;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(rt::DevCounters), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->rayCount.p, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->errorFlag.p, 0, sizeof(int32_t), c->stream));
+    a.counters = wantCounters ? c->counters.p : nullptr;
+    a.rayCount = c->rayCount.p;
+    a.errorFlag = c->errorFlag.p;
+
+    rt::Sky sky;
+    sky.texels = c->sky.p; sky.w = c->skyW; sky.h = c->skyH;
+
+    HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
+    if (a.tileW > 0 && a.tileH > 0) {
+        if (faithful) {
+            rt::RefScene sc;
+            sc.tlas = c->tlas.p; sc.blasOffsets = c->blasOffsets.p; sc.blas = c->blas.p; sc.vtxOffsets = c->vtxOffsets.p;
+            sc.verts = c->verts.p; sc.triOffsets = c->triOffsets.p; sc.tris = c->tris.p; sc.objects = c->objects.p;
+            dim3 grid((width + 7) / 8, (height + 7) / 8);
+            hipLaunchKernelGGL(rt::kFaithful, grid, dim3(64), 0, c->stream, sc, sky, a);
+        } else {
+            hipError_t le = rt::launchFast(c->fast, sky, a, c->stream);
+            if (le != hipSuccess) return failHip(c, le, "fast kernel launch");
+        }
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
+
+    if (out_rgba && !rgbaDev) HIP_TRY(c, hipMemcpyAsync(out_rgba, c->outRgba.p, npix * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (out_prim_id && !idsDev) HIP_TRY(c, hipMemcpyAsync(out_prim_id, c->outIds.p, npix * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (e.out_t && !tDev) HIP_TRY(c, hipMemcpyAsync(e.out_t, c->outT.p, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    rt::DevCounters hc;
+    unsigned long long hr[2] = {0, 0};
+    int32_t herr = 0;
+    HIP_TRY(c, hipMemcpyAsync(&hc, c->counters.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hr, c->rayCount.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&herr, c->errorFlag.p, sizeof(herr), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->evStart, c->evStop));
+    c->lastKernelMs = ms;
+    c->lastRays = hr[0];
+    if (wantCounters) {
+        rtamd_counters* oc = e.out_counters;
+        oc->rays = hc.rays; oc->nodes = hc.nodes; oc->tris = hc.tris; oc->instances = hc.instances; oc->hits = hc.hits;
+        oc->max_blas_stack = hc.maxBlasStack; oc->max_tlas_stack = hc.maxTlasStack; oc->reserved = hc.overflow;
+    }
+    if (herr) return fail(c, RTAMD_ERR_STACK_OVERFLOW, "traversal stack overflow (scene deeper than the shader's stacks allow)");
+    return RTAMD_OK;
+}
+
+int rtamd_last_render_stats(const rtamd_ctx* c, float* ms, uint64_t* rays) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (ms) *ms = c->lastKernelMs;
+    if (rays) *rays = c->lastRays;
+    return RTAMD_OK;
+}
+
+}  // extern "C"
+
+namespace rt {
+// AddShader: Blend SrcAlpha One, no depth (Assets/Shaders/AddShader.shader:11,43-46), onto an
+// 8-bit UNORM target (RayTracingPass.cs:58).
+__global__ void kCompositeAdd(const float4* src, uchar4* dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 s = src[i];
+    uchar4 d = dst[i];
+    float r = saturate((float)d.x / 255.0f + s.x * s.w);
+    float g = saturate((float)d.y / 255.0f + s.y * s.w);
+    float b = saturate((float)d.z / 255.0f + s.z * s.w);
+    float al = saturate((float)d.w / 255.0f + s.w * s.w);
+    dst[i] = make_uchar4((unsigned char)__builtin_floorf(r * 255.0f + 0.5f), (unsigned char)__builtin_floorf(g * 255.0f + 0.5f),
+                         (unsigned char)__builtin_floorf(b * 255.0f + 0.5f), (unsigned char)__builtin_floorf(al * 255.0f + 0.5f));
+}
+}  // namespace rt
+
+extern "C" int rtamd_composite_add(rtamd_ctx* c, const float* src, uint8_t* dst, int32_t width, int32_t height) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!src || !dst || width <= 0 || height <= 0) return fail(c, RTAMD_ERR_INVALID_ARG, "NULL buffer or bad size");
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t n = (size_t)width * height;
+    bool sDev = isDevicePointer(src), dDev = isDevicePointer(dst);
+    if (sDev != dDev) return fail(c, RTAMD_ERR_INVALID_ARG, "src and dst must both be host or both be device memory");
+    const float4* ds = (const float4*)src;
+    uchar4* dd = (uchar4*)dst;
+    DevBuf<uchar4> tmp;
+    if (!sDev) {
+        HIP_TRY(c, c->outRgba.upload((const float4*)src, n, c->stream));
+        HIP_TRY(c, tmp.upload((const uchar4*)dst, n, c->stream));
+        ds = c->outRgba.p; dd = tmp.p;
+    }
+    hipLaunchKernelGGL(rt::kCompositeAdd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ds, dd, n);
+    HIP_TRY(c, hipGetLastError());
+    if (!sDev) HIP_TRY(c, hipMemcpyAsync(dst, dd, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    tmp.release();
+    return RTAMD_OK;
+}

@@ -1,0 +1,206 @@
+"""Seeded, Unity-free scene definitions for the configurations in BASELINE.json.
+
+Every function returns (SceneBuffers, FRAME record, sky (h,w,4) float32).
+Material values come from the reference's prefabs / materials where they exist:
+  metal    specular (0.8,0.8,0.8)      Assets/Prefabs/Sphere.prefab:113-115
+  gold     specular (1,0.78,0.34)      Assets/Prefabs/bunny.001.prefab:100
+  diffuse  albedo 1, specular 0.1      Assets/Prefabs/Wall.prefab:114-115
+  light    emission (1,1,1)            Assets/Material/Wall2.mat:133
+"""
+import os
+
+import numpy as np
+
+from . import host as H
+from . import types as T
+
+
+def procedural_sky(w=256, h=128):
+    """Gradient sky standing in for the missing .exr files: horizon-to-zenith blue/white,
+    a warm band near the sun azimuth, dark ground. Values exceed 1 near the sun (HDR)."""
+    v = (np.arange(h, dtype=np.float32) + 0.5) / h          # 0 = +Y pole after the shader's -theta mapping wraps
+    u = (np.arange(w, dtype=np.float32) + 0.5) / w
+    V, U = np.meshgrid(v, u, indexing="ij")
+    up = np.cos(np.pi * V).astype(np.float32)                 # +1 zenith .. -1 nadir
+    t = np.clip(up * 0.5 + 0.5, 0, 1).astype(np.float32)
+    sky = np.zeros((h, w, 4), dtype=np.float32)
+    sky[..., 0] = 0.9 - 0.6 * t
+    sky[..., 1] = 0.95 - 0.4 * t
+    sky[..., 2] = 1.0 - 0.05 * t
+    sun = np.exp(-((U - 0.3) ** 2) / 0.002 - ((V - 0.35) ** 2) / 0.004).astype(np.float32)
+    sky[..., 0] += 6.0 * sun
+    sky[..., 1] += 5.0 * sun
+    sky[..., 2] += 3.5 * sun
+    ground = up < 0
+    sky[ground, 0:3] *= np.float32(0.25)
+    sky[..., 3] = 1.0
+    return sky
+
+
+def _rot_x(deg):
+    return H.quat_axis_angle((1, 0, 0), deg)
+
+
+def look_at_camera(eye, target, fov, width, height):
+    fwd = np.asarray(target, dtype=np.float64) - np.asarray(eye, dtype=np.float64)
+    q = H.quat_look_rotation(fwd)
+    return H.camera(eye, q, fov, width / height)
+
+
+def few_spheres(width=640, height=360):
+    """Config 1: three instanced UV spheres (one BLAS, 960 triangles), a floor quad and one
+    emissive quad."""
+    sys = H.BuildAccelerateStructureSystem()
+    sphere = sys.BakeBLAS(H.Mesh.uv_sphere(32, 16, 0.5))
+    quad = sys.BakeBLAS(H.Mesh.quad())
+    sys.AddEntity(sphere, H.trs((-1.3, 0.5, 0.0), s=(1, 1, 1)), albedo=(0, 0, 0), specular=(0.8, 0.8, 0.8))
+    sys.AddEntity(sphere, H.trs((0.0, 0.6, 0.4), s=(1.2, 1.2, 1.2)), albedo=(0, 0, 0), specular=(1.0, 0.78, 0.34))
+    sys.AddEntity(sphere, H.trs((1.3, 0.4, -0.3), s=(0.8, 0.8, 0.8)), albedo=(1, 1, 1), specular=(0.1, 0.1, 0.1))
+    sys.AddEntity(quad, H.trs((0, 0, 0), _rot_x(90), (100, 100, 1)), albedo=(1, 1, 1), specular=(0.1, 0.1, 0.1))
+    sys.AddEntity(quad, H.trs((0, 3.0, 0.5), _rot_x(-90), (2, 2, 1)), albedo=(0, 0, 0), specular=(0, 0, 0), emission=(1, 1, 1))
+    buf = sys.OnUpdate()
+    sys.close()
+    frame = look_at_camera((0.0, 1.6, -5.5), (0.0, 0.5, 0.0), 40.0, width, height)
+    return buf, frame, procedural_sky()
+
+
+def random_spheres(width=1920, height=1080, grid=22, tree=H.BuildAccelerateStructureSystem.MEDIAN):
+    """Config 2: floor + grid*grid jittered sphere instances of ONE BLAS (484 at grid=22),
+    radius 0.2-0.5; 80 % Lambert, 15 % metal, 5 % emissive."""
+    sys = H.BuildAccelerateStructureSystem()
+    sphere = sys.BakeBLAS(H.Mesh.uv_sphere(32, 16, 0.5), tree)
+    quad = sys.BakeBLAS(H.Mesh.quad(), tree)
+    sys.AddEntity(quad, H.trs((0, 0, 0), _rot_x(90), (100, 100, 1)), albedo=(0.8, 0.8, 0.8), specular=(0.04, 0.04, 0.04))
+    rp = np.random.RandomState(1)
+    rm = np.random.RandomState(2)
+    spacing = 1.2
+    for iz in range(grid):
+        for ix in range(grid):
+            r = float(rp.uniform(0.2, 0.5))
+            x = (ix - (grid - 1) / 2) * spacing + float(rp.uniform(-0.3, 0.3))
+            z = (iz - (grid - 1) / 2) * spacing + float(rp.uniform(-0.3, 0.3))
+            kind = float(rm.uniform())
+            col = rm.uniform(0.2, 0.9, size=3)
+            if kind < 0.80:
+                mat = dict(albedo=tuple(col), specular=(0.04, 0.04, 0.04))
+            elif kind < 0.95:
+                mat = dict(albedo=(0, 0, 0), specular=tuple(0.6 + 0.4 * (col - 0.2) / 0.7))
+            else:
+                mat = dict(albedo=(0, 0, 0), specular=(0, 0, 0), emission=tuple(4.0 * col))
+            sys.AddEntity(sphere, H.trs((x, r, z), s=(2 * r, 2 * r, 2 * r)), **mat)
+    buf = sys.OnUpdate()
+    sys.close()
+    frame = look_at_camera((0.0, 7.0, -22.0), (0.0, 0.3, -2.0), 38.0, width, height)
+    return buf, frame, procedural_sky()
+
+
+def _bumpy_sphere(segments, rings, seed):
+    """Procedural stand-in for a scanned model: a sphere displaced by a few sine lobes."""
+    m = H.Mesh.uv_sphere(segments, rings, 0.5)
+    rs = np.random.RandomState(seed)
+    p = m.positions.astype(np.float64)
+    n = p / np.linalg.norm(p, axis=1, keepdims=True)
+    disp = np.zeros(len(p))
+    for _ in range(6):
+        k = rs.uniform(2.0, 9.0, size=3)
+        ph = rs.uniform(0, 2 * np.pi)
+        disp += rs.uniform(0.01, 0.05) * np.sin(n @ k + ph)
+    p = n * (0.5 + disp)[:, None]
+    # normals from the displaced surface: area-weighted face normals
+    tri = m.indices
+    fn = np.cross(p[tri[:, 1]] - p[tri[:, 0]], p[tri[:, 2]] - p[tri[:, 0]])
+    vn = np.zeros_like(p)
+    for k in range(3):
+        np.add.at(vn, tri[:, k], fn)
+    ln = np.linalg.norm(vn, axis=1, keepdims=True)
+    vn = np.where(ln > 0, vn / np.maximum(ln, 1e-30), n)
+    return H.Mesh(p.astype(np.float32), vn.astype(np.float32), tri)
+
+
+def mesh_scene(width=1920, height=1080, models_dir=None, target_tris=1_000_000,
+               tree=H.BuildAccelerateStructureSystem.MEDIAN):
+    """Config 3: three unique large meshes (~1 M triangles in total) + three emissive walls.
+
+    With `models_dir` (the reference's Assets/Models) the meshes are peter / bunny / cow
+    subdivided 2 / 3 / 2 times = 1 051 936 triangles; without it, three procedural
+    displaced spheres with the same triangle budget split (61 % / 30 % / 9 %)."""
+    meshes = []
+    if models_dir and os.path.exists(os.path.join(models_dir, "peter.dae")):
+        scale = target_tris / 1_051_936.0
+        rounds = (2, 3, 2) if scale > 0.5 else ((1, 2, 1) if scale > 0.1 else (0, 0, 0))
+        for name, r in zip(("peter", "bunny", "cow"), rounds):
+            meshes.append(H.Mesh.load_dae(os.path.join(models_dir, name + ".dae")).subdivide(r))
+    else:
+        for frac, seed in ((0.61, 11), (0.30, 12), (0.09, 13)):
+            tris = max(64, int(target_tris * frac))
+            rings = max(4, int(round(np.sqrt(tris / 4.0))))      # 2*seg*(rings-1) ~ tris with seg = 2*rings
+            meshes.append(_bumpy_sphere(2 * rings, rings, seed))
+    sys = H.BuildAccelerateStructureSystem()
+    quad = sys.BakeBLAS(H.Mesh.quad(), tree)
+    placements = [((-1.6, 0.0, 0.0), 2.2), ((1.1, -0.2, 0.3), 1.5), ((0.2, -0.55, -1.4), 0.9)]
+    for m, (pos, size) in zip(meshes, placements):
+        ext = (m.positions.max(axis=0) - m.positions.min(axis=0)).max()
+        ctr = (m.positions.max(axis=0) + m.positions.min(axis=0)) * 0.5
+        s = size / float(ext)
+        b = sys.BakeBLAS(m, tree)
+        t = np.asarray(pos, dtype=np.float64) - ctr * s
+        sys.AddEntity(b, H.trs(tuple(t), H.quat_axis_angle((0, 1, 0), 25.0), (s, s, s)), albedo=(1, 1, 1), specular=(0.2, 0.2, 0.2))
+    # walls: the three emissive quads of the reference sub-scene
+    # (Assets/Scenes/SubScenes/RayTracingSubScene.unity:305-307,416-418,567-569), scaled to this scene
+    sys.AddEntity(quad, H.trs((4.0, 1.0, 0.0), H.quat_axis_angle((0, 1, 0), 90), (10, 10, 1)), albedo=(1, 1, 1),
+                  specular=(0.2, 0.2, 0.2), emission=(0, 0.034409046, 1))
+    sys.AddEntity(quad, H.trs((0.0, 1.0, 4.0), H.quat_axis_angle((0, 1, 0), 0), (10, 10, 1)), albedo=(1, 1, 1),
+                  specular=(0.2, 0.2, 0.2), emission=(1, 1, 1))
+    sys.AddEntity(quad, H.trs((-4.0, 1.0, 0.0), H.quat_axis_angle((0, 1, 0), -90), (10, 10, 1)), albedo=(1, 1, 1),
+                  specular=(0.2, 0.2, 0.2), emission=(1, 0, 0))
+    sys.AddEntity(quad, H.trs((0, -1.2, 0), _rot_x(90), (10, 10, 1)), albedo=(0.7, 0.7, 0.7), specular=(0.1, 0.1, 0.1))
+    buf = sys.OnUpdate()
+    sys.close()
+    frame = look_at_camera((0.3, 0.6, -5.0), (0.0, -0.1, 0.0), 45.0, width, height)
+    return buf, frame, procedural_sky()
+
+
+def reference_scene(models_dir, width=1920, height=1080):
+    """The reference's own sample: `peter` + three emissive walls with the sample camera
+    (Assets/Scenes/SubScenes/RayTracingSubScene.unity:151,219-221,305-307,416-418,567-569;
+    Assets/Scenes/SampleScene.unity:638-640,666-667).  Needs the reference's peter.dae."""
+    sys = H.BuildAccelerateStructureSystem()
+    peter = sys.BakeBLAS(H.Mesh.load_dae(os.path.join(models_dir, "peter.dae")))
+    quad = sys.BakeBLAS(H.Mesh.quad())
+    parent = np.array([20.050472, -2.750208, 25.932217])
+    face = dict(albedo=(1, 1, 1), specular=(0.2, 0.2, 0.2))
+    sys.AddEntity(peter, H.trs(tuple(parent + (0, 50, 26.7)), s=(50, 50, 50)), **face)
+    sys.AddEntity(quad, H.trs(tuple(parent + (53, 50, 0.4)), (0, 0.7071068, 0, 0.7071068), (100, 100, 1)),
+                  emission=(0, 0.034409046, 1), **face)
+    sys.AddEntity(quad, H.trs(tuple(parent + (3, 50, -40)), (0, 1, 0, 0), (100, 100, 1)), emission=(1, 1, 1), **face)
+    sys.AddEntity(quad, H.trs(tuple(parent + (-51.8, 50, -9.5)), (0, -0.7033948, 0, 0.71079946), (100, 100, 1)),
+                  emission=(1, 0, 0), **face)
+    buf = sys.OnUpdate()
+    sys.close()
+    frame = H.camera((39.34177, 121.19705, 167.90202), (-0.0028800666, 0.98602176, -0.16570693, -0.017148614),
+                     58.2, width / height, 0.3, 1000.0)
+    return buf, frame, procedural_sky()
+
+
+def instanced_scene(width=1920, height=1080, instances=1250, tris_per_blas=40_000, seed=5):
+    """Config 5 shape: many instances of a few ~40 k-triangle meshes with seeded random
+    transforms (instances * tris_per_blas instanced triangles)."""
+    rs = np.random.RandomState(seed)
+    sys = H.BuildAccelerateStructureSystem()
+    rings = max(4, int(round(np.sqrt(tris_per_blas / 4.0))))
+    blas = [sys.BakeBLAS(_bumpy_sphere(2 * rings, rings, 100 + k)) for k in range(3)]
+    quad = sys.BakeBLAS(H.Mesh.quad())
+    sys.AddEntity(quad, H.trs((0, 0, 0), _rot_x(90), (400, 400, 1)), albedo=(0.8, 0.8, 0.8), specular=(0.04, 0.04, 0.04))
+    side = int(np.ceil(np.sqrt(instances)))
+    for i in range(instances):
+        ix, iz = i % side, i // side
+        s = float(rs.uniform(0.6, 1.4))
+        x = (ix - side / 2) * 2.0 + float(rs.uniform(-0.5, 0.5))
+        z = (iz - side / 2) * 2.0 + float(rs.uniform(-0.5, 0.5))
+        q = H.quat_axis_angle(rs.uniform(-1, 1, size=3) + 1e-3, float(rs.uniform(0, 360)))
+        col = rs.uniform(0.2, 0.9, size=3)
+        sys.AddEntity(blas[i % 3], H.trs((x, 0.8 * s, z), q, (s, s, s)), albedo=tuple(col), specular=(0.04, 0.04, 0.04))
+    buf = sys.OnUpdate()
+    sys.close()
+    frame = look_at_camera((0.0, 14.0, -side * 1.4), (0.0, 0.0, 0.0), 40.0, width, height)
+    return buf, frame, procedural_sky()
