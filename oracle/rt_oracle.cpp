@@ -107,8 +107,11 @@ static inline float3 normalize(float3 v) {
     float l = std::sqrt(dot(v, v));
     return {v.x / l, v.y / l, v.z / l};
 }
+// fminf / fmaxf semantics (the non-NaN operand wins) without the libm call.
+static inline float ofmin(float a, float b) { float r = a < b ? a : b; return b != b ? a : r; }
+static inline float ofmax(float a, float b) { float r = a > b ? a : b; return b != b ? a : r; }
 static inline float3 reflect(float3 i, float3 n) { return i - (2.0f * dot(n, i)) * n; }
-static inline float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+static inline float saturate(float x) { return ofmin(ofmax(x, 0.0f), 1.0f); }
 
 // mul(float4x4 M, float4(v, w)).xyz with M column-major in memory.
 static inline float3 mulPoint(const float* m, float3 v) {
@@ -138,13 +141,13 @@ static inline float acosDecl(float x) {
     p = p * a + 0.0889789874f;
     p = p * a + -0.2145988016f;
     p = p * a + 1.5707963050f;
-    float r = std::sqrt(fmaxf(1.0f - a, 0.0f)) * p;
+    float r = std::sqrt(ofmax(1.0f - a, 0.0f)) * p;
     return x < 0.0f ? PI - r : r;
 }
 // atan2(y,x): atan on [0,1] by the odd polynomial of A&S 4.4.49, octant-unfolded.
 static inline float atan2Decl(float y, float x) {
     float ax = std::fabs(x), ay = std::fabs(y);
-    float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float mx = ofmax(ax, ay), mn = ofmin(ax, ay);
     float a = mx > 0.0f ? mn / mx : 0.0f;
     float s = a * a;
     float p = 0.0028662257f;
@@ -274,11 +277,11 @@ static inline void Raycast(const Node& n, const Ray& ray, float maxFraction, boo
         float nearYt = ly * ray.invDir.y, farYt = hy * ray.invDir.y;
         float lz = n.Lz[i] - ray.origin.z, hz = n.Hz[i] - ray.origin.z;
         float nearZt = lz * ray.invDir.z, farZt = hz * ray.invDir.z;
-        float nearX = fminf(nearXt, farXt), farX = fmaxf(nearXt, farXt);
-        float nearY = fminf(nearYt, farYt), farY = fmaxf(nearYt, farYt);
-        float nearZ = fminf(nearZt, farZt), farZ = fmaxf(nearZt, farZt);
-        float nearMax = fmaxf(fmaxf(fmaxf(nearX, nearY), nearZ), 0.0f);
-        float farMin = fminf(fminf(fminf(farX, farY), farZ), maxFraction);
+        float nearX = ofmin(nearXt, farXt), farX = ofmax(nearXt, farXt);
+        float nearY = ofmin(nearYt, farYt), farY = ofmax(nearYt, farYt);
+        float nearZ = ofmin(nearZt, farZt), farZ = ofmax(nearZt, farZt);
+        float nearMax = ofmax(ofmax(ofmax(nearX, nearY), nearZ), 0.0f);
+        float farMin = ofmin(ofmin(ofmin(farX, farY), farZ), maxFraction);
         hit[i] = nearMax <= farMin;
     }
 }
@@ -462,7 +465,7 @@ static inline void GetTangentSpace(float3 normal, float3& tangent, float3& binor
 // Uniform (not cosine-weighted) hemisphere sample.  .compute:67-76
 static inline float3 SampleHemisphere(float3 normal, float u1, float u2) {
     float cosTheta = u1;
-    float sinTheta = std::sqrt(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+    float sinTheta = std::sqrt(ofmax(0.0f, 1.0f - cosTheta * cosTheta));
     float sphi, cphi;
     sincos2piDecl(u2, sphi, cphi);
     float3 ts = f3(cphi * sinTheta, sphi * sinTheta, cosTheta);
@@ -487,8 +490,8 @@ static inline float3 tracePath(Tracer& tr, Ray ray, uint32_t key, int maxBounces
         L = L + energy * hit.emission;
         if (b >= maxBounces) break;
         float3 spec = hit.specular;
-        float3 alb = f3(fminf(1.0f - spec.x, hit.albedo.x), fminf(1.0f - spec.y, hit.albedo.y),
-                        fminf(1.0f - spec.z, hit.albedo.z));
+        float3 alb = f3(ofmin(1.0f - spec.x, hit.albedo.x), ofmin(1.0f - spec.y, hit.albedo.y),
+                        ofmin(1.0f - spec.z, hit.albedo.z));
         float specChance = energyOf(spec);
         float diffChance = energyOf(alb);
         float sum = specChance + diffChance;

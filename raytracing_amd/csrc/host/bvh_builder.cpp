@@ -304,11 +304,9 @@ int bvhBuild(rtamd_point_and_index* points, const rtamd_aabb* aabbs, int n, rtam
 int bvhBuildJobs(rtamd_point_and_index* points, const rtamd_aabb* aabbs, int n, rtamd_node* nodes, int capacity,
                  int* branchCountOut) {
     if (capacity < 2 || n <= 0) return RTAMD_ERR_INVALID_ARG;
-    Range level0Buf[kMaxNumTreeBranches], level1Buf[kMaxNumTreeBranches + 4];
-    Range level0Extra[kMaxNumTreeBranches + 4];
-    Range* level0 = level0Extra;
-    Range* level1 = level1Buf;
-    (void)level0Buf;
+    Range levelA[kMaxNumTreeBranches + 4], levelB[kMaxNumTreeBranches + 4];
+    Range* level0 = levelA;
+    Range* level1 = levelB;
     int level0Size = 1, level1Size = 0;
 
     Range root;
@@ -324,11 +322,14 @@ int bvhBuildJobs(rtamd_point_and_index* points, const rtamd_aabb* aabbs, int n, 
     builder.nodes = nodes; builder.capacity = capacity; builder.points = points; builder.freeNodeIndex = 0;
 
     Range subRanges[4];
+    bool anySplit;
     do {
         minTreeNodeLevel = kMaxTreeDepth;
+        anySplit = false;
         for (int i = 0; i < level0Size; ++i) {
             if (level0[i].Depth <= kMaxTreeDepth && level0[i].Length > kSmallRangeSize &&
                 level1Size <= maxNumBranchesMinusOneSplit) {
+                anySplit = true;
                 builder.processLargeRange(level0[i], subRanges);
                 builder.createInternalNodes(subRanges, 4, level0[i].Root, level1, level1Size, freeNodeIndex);
                 for (int k = 0; k < 4; k++) largestRangeInLastLevel = std::max(largestRangeInLastLevel, subRanges[k].Length);
@@ -342,7 +343,11 @@ int bvhBuildJobs(rtamd_point_and_index* points, const rtamd_aabb* aabbs, int n, 
         std::swap(level0, level1);
         level0Size = level1Size;
         level1Size = 0;
-    } while (level0Size <= maxNumBranchesMinusOneSplit && largestRangeInLastLevel > kSmallRangeSize &&
+        // The reference never resets largestRangeInLastLevel (:655,:678-681,:688), so for roughly
+        // 129..900 primitives its loop condition stays true after the last possible split and
+        // the loop spins forever on an unchanging state.  Leaving once a pass splits nothing
+        // yields exactly that fixed state.
+    } while (anySplit && level0Size <= maxNumBranchesMinusOneSplit && largestRangeInLastLevel > kSmallRangeSize &&
              minTreeNodeLevel <= kMaxTreeDepth);
     if (builder.failed) return RTAMD_ERR_BAD_INDEX;
 
