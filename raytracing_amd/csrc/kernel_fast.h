@@ -16,9 +16,10 @@
 //     exactly in a box face makes that test fail (0 * inf = NaN is ignored by min/max),
 //     and the reference then never sees the triangle.
 //
-// Layout (all arrays 128-byte aligned in HBM):
-//   WNode  128 B  lx,hx,ly,hy,lz,hz (float4 = the four children), child[4], pad
-//   FTri    64 B  (v0, original index) (e1, lo.x) (e2, lo.y) (lo.z, hi) — in reference visiting order
+// Layout (arrays 128-byte aligned in HBM; a lane's node is exactly one 128-byte line):
+//   WNode  128 B  lx,hx,ly,hy,lz,hz (float4 = the four children), child[4], pad;
+//                 BLAS nodes first, the TLAS nodes appended behind them
+//   FTri    64 B  (lo.xyz,hi.x)(hi.yz,index,v0.x)(v0.yz,e1.xy)(e1.z,e2.xyz) — visiting order
 //   FNrm    48 B  n0,n1,n2                                   — read once per closest hit
 //   FInst   64 B  three rows of WorldToLocal, BLAS root, original object index
 //   FShade  96 B  three rows of LocalToWorld, albedo, specular, emission
@@ -38,26 +39,25 @@ struct alignas(128) WNode {
     int4 child;
     int4 pad;
 };
-struct alignas(64) FTri { float4 v0; float4 e1; float4 e2; float4 bx; };  // v0.w = original index (bits); box = (e1.w, e2.w, bx.x) .. (bx.y, bx.z, bx.w)
+struct alignas(64) FTri { float4 a, b, c, d; };
 struct alignas(16) FNrm { float4 a, b, c; };                            // n0.xyz n1.x | n1.yz n2.xy | n2.z
 struct alignas(64) FInst { float4 r0, r1, r2; int32_t root, object, pad0, pad1; };
 struct alignas(32) FShade { float4 r0, r1, r2; float4 albedo, specular, emission; };
 
+// child / stack words: >= 0 node index; < 0: ~payload, payload bit 30 set = instance rank,
+// clear = (first triangle << 2 | count-1).  kEmptyChild never reaches the stack.
 constexpr int32_t kEmptyChild = (int32_t)0x80000001;
-constexpr int32_t kSentinel = (int32_t)0x80000000;   // "leave the instance" marker on the stack
+constexpr uint32_t kInstanceBit = 0x40000000u;
 
 struct FastScene {
-    const WNode* tlasNodes;
-    const WNode* blasNodes;
+    const WNode* nodes;
     const FInst* inst;
     const FShade* shade;
     const FTri* tris;
     const FNrm* nrms;
     const int32_t* superTiles;   // ids of the 32x32 pixel tiles this launch owns
     int32_t nSuperTiles;
-    int32_t tlasRoot;            // index of the TLAS root in tlasNodes
-    int32_t* overflow;           // spill area for stacks deeper than the LDS part
-    int32_t overflowStride;      // lanes in the grid
+    int32_t tlasRoot;            // index of the TLAS root in nodes
 };
 
 template <typename T>
@@ -82,23 +82,23 @@ struct DBuf {
 
 // Host-side owner of the GPU layout.
 struct FastSceneHost {
-    DBuf<WNode> tlasNodes, blasNodes;
+    DBuf<WNode> nodes;
     DBuf<FInst> inst;
     DBuf<FShade> shade;
     DBuf<FTri> tris;
     DBuf<FNrm> nrms;
     DBuf<int32_t> superTiles;
-    DBuf<int32_t> overflow;
     std::vector<int32_t> blasRoot;     // wide-node index of each BLAS root
-    std::vector<WNode> hTlas;          // staging kept alive until the copy is done
+    std::vector<WNode> hNodes;         // BLAS nodes, then the TLAS nodes of the last upload
+    size_t nBlasNodes = 0;
     std::vector<FInst> hInst;
     std::vector<FShade> hShade;
     std::vector<int32_t> hSuper;
     int nInst = 0;
+    int tlasRoot = 0;
 
     void release() {
-        tlasNodes.release(); blasNodes.release(); inst.release(); shade.release(); tris.release(); nrms.release();
-        superTiles.release(); overflow.release();
+        nodes.release(); inst.release(); shade.release(); tris.release(); nrms.release(); superTiles.release();
     }
 
     static void setChildBox(WNode& w, int slot, const rtamd_node& n, int i) {
@@ -117,12 +117,14 @@ struct FastSceneHost {
                            const int32_t* vtxOffsets, const rtamd_vertex* verts, const int32_t* triOffsets,
                            const rtamd_int3* tris_, const int32_t* triCount, int nBlas, hipStream_t stream,
                            std::string& err) {
-        std::vector<WNode> wn;
+        (void)triCount;
+        std::vector<WNode>& wn = hNodes;
+        wn.clear();
         std::vector<FTri> ft;
         std::vector<FNrm> fn;
         blasRoot.assign(nBlas, 0);
         for (int b = 0; b < nBlas; b++) {
-            const rtamd_node* nodes = blas + blasOffsets[b];
+            const rtamd_node* nodes_ = blas + blasOffsets[b];
             int nn = nodeCount[b];
             const rtamd_int3* tri = tris_ + triOffsets[b];
             const rtamd_vertex* vtx = verts + vtxOffsets[b];
@@ -136,7 +138,7 @@ struct FastSceneHost {
             while (!st.empty()) {
                 int ni = st.back();
                 st.pop_back();
-                const rtamd_node& n = nodes[ni];
+                const rtamd_node& n = nodes_[ni];
                 if (n.Flags == 0) {
                     wideIndex[ni] = (int32_t)(wn.size() + order.size());
                     order.push_back(ni);
@@ -149,13 +151,16 @@ struct FastSceneHost {
                         const float* p0 = vtx[tri[t].x].position;
                         const float* p1 = vtx[tri[t].y].position;
                         const float* p2 = vtx[tri[t].z].position;
-                        FTri f;
-                        f.v0 = make_float4(p0[0], p0[1], p0[2], 0.f);
-                        std::memcpy(&f.v0.w, &t, 4);
                         // e1 = v1 - v0, e2 = v2 - v0: the same binary32 subtractions Trisection does (:201-202)
-                        f.e1 = make_float4(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], n.Lx[i]);
-                        f.e2 = make_float4(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2], n.Ly[i]);
-                        f.bx = make_float4(n.Lz[i], n.Hx[i], n.Hy[i], n.Hz[i]);
+                        float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+                        float e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+                        float idx;
+                        std::memcpy(&idx, &t, 4);
+                        FTri f;
+                        f.a = make_float4(n.Lx[i], n.Ly[i], n.Lz[i], n.Hx[i]);
+                        f.b = make_float4(n.Hy[i], n.Hz[i], idx, p0[0]);
+                        f.c = make_float4(p0[1], p0[2], e1[0], e1[1]);
+                        f.d = make_float4(e1[2], e2[0], e2[1], e2[2]);
                         ft.push_back(f);
                         const float* n0 = vtx[tri[t].x].normal;
                         const float* n1 = vtx[tri[t].y].normal;
@@ -175,22 +180,21 @@ struct FastSceneHost {
                 uint32_t start = (uint32_t)(triBase + leafStart[ni]);
                 return ~(int32_t)((start << 2) | (uint32_t)(leafCnt[ni] - 1));
             };
-            if (nodes[1].Flags != 0) {
+            if (nodes_[1].Flags != 0) {
                 // a tree whose root is itself a leaf node: wrap it so the kernel always starts at a node
                 WNode w;
                 std::memset(&w, 0, sizeof(w));
                 for (int s = 0; s < 4; s++) setEmptyBox(w, s);
-                int32_t ch[4] = {kEmptyChild, kEmptyChild, kEmptyChild, kEmptyChild};
-                const rtamd_node& n = nodes[1];
+                const rtamd_node& n = nodes_[1];
                 float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
                 for (int i = 0; i < 4; i++) {
                     if (n.Data[i] == -1) continue;
                     lo[0] = std::fmin(lo[0], n.Lx[i]); lo[1] = std::fmin(lo[1], n.Ly[i]); lo[2] = std::fmin(lo[2], n.Lz[i]);
                     hi[0] = std::fmax(hi[0], n.Hx[i]); hi[1] = std::fmax(hi[1], n.Hy[i]); hi[2] = std::fmax(hi[2], n.Hz[i]);
                 }
-                ch[0] = leafCode(1);
-                w.lx.x = lo[0]; w.ly.x = lo[1]; w.lz.x = lo[2]; w.hx.x = hi[0]; w.hy.x = hi[1]; w.hz.x = hi[2];
-                w.child = make_int4(ch[0], ch[1], ch[2], ch[3]);
+                int32_t c0 = leafCode(1);
+                if (c0 != kEmptyChild) { w.lx.x = lo[0]; w.ly.x = lo[1]; w.lz.x = lo[2]; w.hx.x = hi[0]; w.hy.x = hi[1]; w.hz.x = hi[2]; }
+                w.child = make_int4(c0, kEmptyChild, kEmptyChild, kEmptyChild);
                 blasRoot[b] = (int32_t)wn.size();
                 wn.push_back(w);
                 continue;
@@ -198,7 +202,7 @@ struct FastSceneHost {
             blasRoot[b] = wideIndex[1];
             // pass 2: emit the internal nodes in the same order
             for (int ni : order) {
-                const rtamd_node& n = nodes[ni];
+                const rtamd_node& n = nodes_[ni];
                 WNode w;
                 std::memset(&w, 0, sizeof(w));
                 int32_t ch[4];
@@ -206,36 +210,39 @@ struct FastSceneHost {
                     int c = n.Data[i];
                     if (c == 0) { ch[i] = kEmptyChild; setEmptyBox(w, i); continue; }
                     setChildBox(w, i, n, i);
-                    ch[i] = nodes[c].Flags == 0 ? wideIndex[c] : leafCode(c);
+                    ch[i] = nodes_[c].Flags == 0 ? wideIndex[c] : leafCode(c);
                     if (ch[i] == kEmptyChild) setEmptyBox(w, i);
                 }
                 w.child = make_int4(ch[0], ch[1], ch[2], ch[3]);
                 wn.push_back(w);
             }
         }
+        nBlasNodes = wn.size();
         hipError_t e;
-        if ((e = blasNodes.put(wn, stream)) != hipSuccess) return e;
         if ((e = tris.put(ft, stream)) != hipSuccess) return e;
         if ((e = nrms.put(fn, stream)) != hipSuccess) return e;
-        return hipStreamSynchronize(stream);   // the staging vectors die with this scope
+        return hipStreamSynchronize(stream);   // ft / fn die with this scope; the nodes go up with the TLAS
     }
 
-    // Re-pack the TLAS (node for node) and the per-object data, instances in visiting order.
+    // Re-pack the TLAS (node for node) behind the BLAS nodes, and the per-object data with
+    // instances in visiting order.
     hipError_t buildTop(const rtamd_node* tlas, int nTlas, const rtamd_object_property* objects, int nObjects,
                         hipStream_t stream, std::string& err) {
         (void)nObjects;
-        hTlas.clear(); hInst.clear(); hShade.clear();
+        hNodes.resize(nBlasNodes);
+        hInst.clear(); hShade.clear();
         std::vector<int32_t> wideIndex(nTlas, -1), order, st;
         st.push_back(1);
         while (!st.empty()) {
             int ni = st.back();
             st.pop_back();
-            wideIndex[ni] = (int32_t)order.size();
+            wideIndex[ni] = (int32_t)(nBlasNodes + order.size());
             order.push_back(ni);
             const rtamd_node& n = tlas[ni];
             if (n.Flags == 0)
                 for (int i = 0; i < 4; i++) if (n.Data[i] != 0) st.push_back(n.Data[i]);
         }
+        tlasRoot = (int)nBlasNodes;
         for (int ni : order) {
             const rtamd_node& n = tlas[ni];
             WNode w;
@@ -248,7 +255,7 @@ struct FastSceneHost {
                 setChildBox(w, i, n, i);
                 if (n.Flags == 0) { ch[i] = wideIndex[d]; continue; }
                 const rtamd_object_property& o = objects[d];
-                int rank = (int)hInst.size();
+                uint32_t rank = (uint32_t)hInst.size();
                 FInst fi;
                 const float* m = o.WorldToLocal;
                 fi.r0 = make_float4(m[0], m[4], m[8], m[12]);
@@ -265,15 +272,16 @@ struct FastSceneHost {
                 fs.specular = make_float4(o.specular[0], o.specular[1], o.specular[2], o.specular[3]);
                 fs.emission = make_float4(o.emission[0], o.emission[1], o.emission[2], o.emission[3]);
                 hShade.push_back(fs);
-                ch[i] = ~rank;
+                ch[i] = ~(int32_t)(rank | kInstanceBit);
             }
             w.child = make_int4(ch[0], ch[1], ch[2], ch[3]);
-            hTlas.push_back(w);
+            hNodes.push_back(w);
         }
         if (hInst.empty()) { err = "TLAS references no object"; return hipSuccess; }
+        if (hInst.size() >= kInstanceBit) { err = "too many instances"; return hipSuccess; }
         nInst = (int)hInst.size();
         hipError_t e;
-        if ((e = tlasNodes.put(hTlas, stream)) != hipSuccess) return e;
+        if ((e = nodes.put(hNodes, stream)) != hipSuccess) return e;
         if ((e = inst.put(hInst, stream)) != hipSuccess) return e;
         return shade.put(hShade, stream);
     }
@@ -282,9 +290,10 @@ struct FastSceneHost {
 // ------------------------------------------------------------------ kernel ---
 
 constexpr int kBlockThreads = 256;
-constexpr int kLdsStack = 32;        // stack entries per lane held in LDS
-constexpr int kMaxStack = 256;       // total, as the reference's BLAS stack (.compute:93)
+constexpr int kLdsStack = 40;        // stack entries per lane, all in LDS: [entry][thread], conflict-free
 constexpr int kModeRef = 0, kModePt = 1, kModePrimary = 2;
+
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct FastHit {
     float t, u, v;
@@ -303,19 +312,21 @@ __device__ __forceinline__ V3 rowsDir(float4 r0, float4 r1, float4 r2, V3 v) {
               (r2.x * v.x + r2.y * v.y) + r2.z * v.z);
 }
 
-// One child of the four-box test (.compute:233-263): entry distance, or +inf if missed.
-__device__ __forceinline__ float slabNear(float lo_x, float hi_x, float lo_y, float hi_y, float lo_z, float hi_z,
-                                          const Ray& r, float maxFraction) {
-    float nearXt = (lo_x - r.origin.x) * r.invDir.x, farXt = (hi_x - r.origin.x) * r.invDir.x;
-    float nearYt = (lo_y - r.origin.y) * r.invDir.y, farYt = (hi_y - r.origin.y) * r.invDir.y;
-    float nearZt = (lo_z - r.origin.z) * r.invDir.z, farZt = (hi_z - r.origin.z) * r.invDir.z;
-    float nearX = fmin_(nearXt, farXt), farX = fmax_(nearXt, farXt);
-    float nearY = fmin_(nearYt, farYt), farY = fmax_(nearYt, farYt);
-    float nearZ = fmin_(nearZt, farZt), farZ = fmax_(nearZt, farZt);
-    float nearMax = fmax_(fmax_(fmax_(nearX, nearY), nearZ), 0.0f);
-    float farMin = fmin_(fmin_(fmin_(farX, farY), farZ), maxFraction);
-    return nearMax <= farMin ? nearMax : RT_INF;
+// The four-box slab test (.compute:233-263), two children per packed instruction.  The
+// products and differences are the same binary32 operations as the scalar form.
+__device__ __forceinline__ void slabPair(f2 lx, f2 hx, f2 ly, f2 hy, f2 lz, f2 hz, f2 ox, f2 oy, f2 oz, f2 ix, f2 iy,
+                                         f2 iz, float maxFraction, float& dA, float& dB) {
+    f2 nxt = (lx - ox) * ix, fxt = (hx - ox) * ix;
+    f2 nyt = (ly - oy) * iy, fyt = (hy - oy) * iy;
+    f2 nzt = (lz - oz) * iz, fzt = (hz - oz) * iz;
+    float nearA = fmax_(fmax_(fmax_(fmin_(nxt.x, fxt.x), fmin_(nyt.x, fyt.x)), fmin_(nzt.x, fzt.x)), 0.0f);
+    float farA = fmin_(fmin_(fmin_(fmax_(nxt.x, fxt.x), fmax_(nyt.x, fyt.x)), fmax_(nzt.x, fzt.x)), maxFraction);
+    float nearB = fmax_(fmax_(fmax_(fmin_(nxt.y, fxt.y), fmin_(nyt.y, fyt.y)), fmin_(nzt.y, fzt.y)), 0.0f);
+    float farB = fmin_(fmin_(fmin_(fmax_(nxt.y, fxt.y), fmax_(nyt.y, fyt.y)), fmax_(nzt.y, fzt.y)), maxFraction);
+    dA = nearA <= farA ? nearA : RT_INF;
+    dB = nearB <= farB ? nearB : RT_INF;
 }
+
 __device__ __forceinline__ bool slabHit(float lo_x, float hi_x, float lo_y, float hi_y, float lo_z, float hi_z,
                                         const Ray& r, float maxFraction) {
     float nearXt = (lo_x - r.origin.x) * r.invDir.x, farXt = (hi_x - r.origin.x) * r.invDir.x;
@@ -354,21 +365,27 @@ __device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world
     s.specular = v3(fs.specular.x, fs.specular.y, fs.specular.z);
     s.emission = v3(fs.emission.x, fs.emission.y, fs.emission.z);
     s.object = fi.object;
-    s.triangle = __float_as_int(sc.tris[h.tri].v0.w);
+    s.triangle = __float_as_int(sc.tris[h.tri].b.z);
     return s;
 }
 
 // Persistent kernel.  Each lane owns one pixel at a time and walks all of its samples
-// and bounces, so a pixel's sum is formed in a fixed order.  Lanes whose ray has
-// finished wait until enough of the wave is waiting, then shade / start new rays /
-// fetch new pixels together (ballot-driven regrouping); the wave draws pixels from one
-// global counter in 8x8 tiles.
+// and bounces, so a pixel's sum is formed in a fixed order.  Three levels of regrouping,
+// all driven by wave ballots:
+//   * lanes whose ray has finished wait until fewer than `refillBelow` lanes are still
+//     traversing, then shade / start new rays / fetch new pixels together;
+//   * inside traversal, lanes that reached a leaf (triangles or an instance) wait while at
+//     least `nodeMin` lanes still have inner nodes to test, then all leaves are handled
+//     together;
+//   * the wave draws pixels from one global counter, 8x8 pixel tiles first.
+// The traversal stack lives in LDS ([entry][thread], one bank per lane).  A ray that
+// needs more than kLdsStack entries raises the error flag; the host then repeats the frame
+// with the reference-order kernel, whose stacks have the reference's own capacity.
 template <int MODE>
-__global__ __launch_bounds__(kBlockThreads) void kFast(FastScene sc, Sky sky, RenderArgs a, int refillBelow) {
+__global__ __launch_bounds__(kBlockThreads) void kFast(FastScene sc, Sky sky, RenderArgs a, int refillBelow, int nodeMin) {
     __shared__ int32_t ldsStack[kLdsStack][kBlockThreads];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int gl = blockIdx.x * kBlockThreads + tid;
     const unsigned long long totalWork = (unsigned long long)sc.nSuperTiles * 1024ull;
 
     // pixel state
@@ -388,26 +405,23 @@ __global__ __launch_bounds__(kBlockThreads) void kFast(FastScene sc, Sky sky, Re
     FastHit best;
     best.t = RT_INF; best.u = best.v = 0; best.inst = -1; best.tri = -1;
     int32_t node = 0;
-    int sp = 0;
-    bool inBlas = false;
+    int sp = 0, spMax = 0;
+    int instSp = -1;          // stack height on entering the current instance, -1 outside
     int32_t curInst = -1;
     uint32_t rays = 0;
-    bool overflowed = false;
 
-    // The LDS part and the spill part are accessed by separate statements on purpose: an
-    // if/else over the two address spaces gets merged into one flat access by the optimiser.
-#define RT_PUSH(v)                                                                                      \
-    do {                                                                                                \
-        const int32_t pv_ = (v);                                                                        \
-        if (sp < kLdsStack) ldsStack[sp][tid] = pv_;                                                    \
-        if (sp >= kLdsStack && sp < kMaxStack) sc.overflow[(size_t)(sp - kLdsStack) * sc.overflowStride + gl] = pv_; \
-        if (sp >= kMaxStack) overflowed = true; else sp++;                                              \
+#define RT_PUSH(v)                                                        \
+    do {                                                                  \
+        ldsStack[sp < kLdsStack ? sp : kLdsStack - 1][tid] = (v);         \
+        sp++;                                                             \
+        spMax = sp > spMax ? sp : spMax;                                  \
     } while (0)
-#define RT_POP(dst)                                                                                     \
-    do {                                                                                                \
-        sp--;                                                                                           \
-        dst = ldsStack[sp < kLdsStack ? sp : kLdsStack - 1][tid];                                       \
-        if (sp >= kLdsStack) dst = sc.overflow[(size_t)(sp - kLdsStack) * sc.overflowStride + gl];      \
+    // next stack entry; leaving an instance restores the world-space ray (.compute:377 returns)
+#define RT_POP()                                                          \
+    do {                                                                  \
+        if (sp == instSp) { cur = world; curInst = -1; instSp = -1; }     \
+        if (sp == 0) { trav = false; node = 0; }                          \
+        else { sp--; node = ldsStack[sp < kLdsStack ? sp : kLdsStack - 1][tid]; } \
     } while (0)
 
     for (;;) {
@@ -470,7 +484,7 @@ __global__ __launch_bounds__(kBlockThreads) void kFast(FastScene sc, Sky sky, Re
             }
             // fetch pixels for lanes that have none: one atomic per wave and round, shared by ballot
             for (;;) {
-                bool need = !trav && !haveRay && !pixelActive && !noMoreWork;
+                bool need = !haveRay && !pixelActive && !noMoreWork;
                 unsigned long long m = __ballot(need);
                 if (m == 0ull) break;
                 int leader = __ffsll((long long)m) - 1;
@@ -509,91 +523,115 @@ __global__ __launch_bounds__(kBlockThreads) void kFast(FastScene sc, Sky sky, Re
             if (haveRay) {
                 world = next; cur = next;
                 best.t = RT_INF; best.inst = -1; best.tri = -1;
-                node = sc.tlasRoot; sp = 0; inBlas = false;
+                node = sc.tlasRoot; sp = 0; instSp = -1; curInst = -1;
                 trav = true;
                 rays++;
             }
         }
+        if (__ballot(trav) == 0ull) break;   // nobody got a ray: every lane is out of work
+
         // ------------------------------------------------ phase B: traversal
-        unsigned long long active = __ballot(trav);
-        if (active == 0ull) {
-            // nobody got a ray: every lane is out of work
-            break;
-        }
         for (;;) {
-            if (trav) {
-                if (node >= 0) {
-                    const WNode* nb = inBlas ? sc.blasNodes : sc.tlasNodes;
-                    const float4* np = reinterpret_cast<const float4*>(nb + node);
-                    float4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5];
-                    int4 ch = reinterpret_cast<const int4*>(np)[6];
-                    float d0 = slabNear(lx.x, hx.x, ly.x, hy.x, lz.x, hz.x, cur, best.t);
-                    float d1 = slabNear(lx.y, hx.y, ly.y, hy.y, lz.y, hz.y, cur, best.t);
-                    float d2 = slabNear(lx.z, hx.z, ly.z, hy.z, lz.z, hz.z, cur, best.t);
-                    float d3 = slabNear(lx.w, hx.w, ly.w, hy.w, lz.w, hz.w, cur, best.t);
+            // B1: inner nodes, for as long as enough lanes have one
+            for (;;) {
+                const bool atNode = trav && node >= 0;
+                const unsigned long long nm = __ballot(atNode);
+                if (nm == 0ull) break;
+                if (__popcll(nm) < nodeMin && __ballot(trav && node < 0) != 0ull) break;
+                if (atNode) {
+                    const float4* np = reinterpret_cast<const float4*>(sc.nodes + node);
+                    const float4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5];
+                    const int4 ch = reinterpret_cast<const int4*>(np)[6];
+                    const f2 ox = {cur.origin.x, cur.origin.x}, oy = {cur.origin.y, cur.origin.y}, oz = {cur.origin.z, cur.origin.z};
+                    const f2 ix = {cur.invDir.x, cur.invDir.x}, iy = {cur.invDir.y, cur.invDir.y}, iz = {cur.invDir.z, cur.invDir.z};
+                    float d0, d1, d2, d3;
+                    slabPair(f2{lx.x, lx.y}, f2{hx.x, hx.y}, f2{ly.x, ly.y}, f2{hy.x, hy.y}, f2{lz.x, lz.y}, f2{hz.x, hz.y},
+                             ox, oy, oz, ix, iy, iz, best.t, d0, d1);
+                    slabPair(f2{lx.z, lx.w}, f2{hx.z, hx.w}, f2{ly.z, ly.w}, f2{hy.z, hy.w}, f2{lz.z, lz.w}, f2{hz.z, hz.w},
+                             ox, oy, oz, ix, iy, iz, best.t, d2, d3);
                     int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
                     if (c0 == kEmptyChild) d0 = RT_INF;
                     if (c1 == kEmptyChild) d1 = RT_INF;
                     if (c2 == kEmptyChild) d2 = RT_INF;
                     if (c3 == kEmptyChild) d3 = RT_INF;
-                    int nh = (d0 < RT_INF) + (d1 < RT_INF) + (d2 < RT_INF) + (d3 < RT_INF);
-                    // sort by entry distance (misses = +inf go last)
+                    const int nh = (d0 < RT_INF) + (d1 < RT_INF) + (d2 < RT_INF) + (d3 < RT_INF);
+                    // nearest first: sort by entry distance (misses = +inf go last), push far to near
                     cswap(d0, c0, d1, c1); cswap(d2, c2, d3, c3); cswap(d0, c0, d2, c2); cswap(d1, c1, d3, c3); cswap(d1, c1, d2, c2);
                     if (nh > 3) RT_PUSH(c3);
                     if (nh > 2) RT_PUSH(c2);
                     if (nh > 1) RT_PUSH(c1);
-                    node = nh > 0 ? c0 : kSentinel + 2;   // "+2" = pop marker
-                } else if (!inBlas) {
+                    if (nh > 0) node = c0;
+                    else RT_POP();
+                }
+            }
+            // B2: leaves
+            if (trav && node < 0) {
+                const uint32_t code = (uint32_t)~node;
+                if (code & kInstanceBit) {
                     // enter an instance (.compute:279-287)
-                    int rank = ~node;
+                    const int rank = (int)(code & (kInstanceBit - 1u));
                     const FInst fi = sc.inst[rank];
                     cur = makeRay(rowsPoint(fi.r0, fi.r1, fi.r2, world.origin), rowsDir(fi.r0, fi.r1, fi.r2, world.direction));
-                    RT_PUSH(kSentinel);
+                    instSp = sp;
                     node = fi.root;
-                    inBlas = true;
                     curInst = rank;
                 } else {
-                    uint32_t code = (uint32_t)~node;
-                    uint32_t start = code >> 2;
-                    int cnt = (int)(code & 3u) + 1;
+                    const uint32_t start = code >> 2;
+                    const int cnt = (int)(code & 3u) + 1;
                     const float tEntry = best.t;   // the reference masks all four slots before testing any (:298)
-                    for (int k = 0; k < cnt; k++) {
-                        const FTri tr = sc.tris[start + k];
-                        if (!slabHit(tr.e1.w, tr.bx.y, tr.e2.w, tr.bx.z, tr.bx.x, tr.bx.w, cur, tEntry)) continue;
+                    uint32_t mask = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (k < cnt) {
+                            const float4* tp = reinterpret_cast<const float4*>(sc.tris + start + k);
+                            const float4 A = tp[0], B = tp[1];
+                            if (slabHit(A.x, A.w, A.y, B.x, A.z, B.y, cur, tEntry)) mask |= 1u << k;
+                        }
+                    }
+                    while (mask) {
+                        const int k = __ffs(mask) - 1;
+                        mask &= mask - 1u;
+                        const float4* tp = reinterpret_cast<const float4*>(sc.tris + start + k);
+                        const float4 B = tp[1], C = tp[2], D = tp[3];
                         float t, u, v;
-                        if (trisect(cur.origin, cur.direction, v3(tr.v0.x, tr.v0.y, tr.v0.z), v3(tr.e1.x, tr.e1.y, tr.e1.z),
-                                    v3(tr.e2.x, tr.e2.y, tr.e2.z), t, u, v)) {
-                            int32_t ti = (int32_t)(start + k);
-                            bool closer = t < best.t;
-                            bool tie = t == best.t && (curInst < best.inst || (curInst == best.inst && ti < best.tri));
+                        if (trisect(cur.origin, cur.direction, v3(B.w, C.x, C.y), v3(C.z, C.w, D.x), v3(D.y, D.z, D.w), t, u, v)) {
+                            const int32_t ti = (int32_t)(start + k);
+                            const bool closer = t < best.t;
+                            const bool tie = t == best.t && (curInst < best.inst || (curInst == best.inst && ti < best.tri));
                             if (closer || tie) { best.t = t; best.u = u; best.v = v; best.inst = curInst; best.tri = ti; }
                         }
                     }
-                    node = kSentinel + 2;
-                }
-                // pop
-                while (node == kSentinel + 2) {
-                    if (sp == 0) { trav = false; break; }
-                    RT_POP(node);
-                    if (node == kSentinel) { cur = world; inBlas = false; node = kSentinel + 2; }
+                    RT_POP();
                 }
             }
-            unsigned long long m = __ballot(trav);
-            if (m == 0ull) break;
-            if (__popcll(m) < refillBelow) {
+            const unsigned long long tm = __ballot(trav);
+            if (tm == 0ull) break;
+            if (__popcll(tm) < refillBelow) {
                 // leave only if some waiting lane can actually be given a new ray
-                bool canRefill = !trav && !(noMoreWork && !pixelActive && !pathActive);
+                const bool canRefill = !trav && !(noMoreWork && !pixelActive && !pathActive);
                 if (__ballot(canRefill) != 0ull) break;
             }
         }
     }
 #undef RT_PUSH
 #undef RT_POP
-    if (overflowed) atomicOr(a.errorFlag, 1);
+    if (spMax > kLdsStack) atomicOr(a.errorFlag, 2);
     unsigned long long r = rays;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
     if (lane == 0 && r) atomicAdd(a.rayCount, r);
+}
+
+struct FastLaunchConfig {
+    int blocksPerCU = 4, refillBelow = 40, nodeMin = 16;
+};
+
+inline FastLaunchConfig fastLaunchConfig() {
+    FastLaunchConfig c;
+    if (const char* s = getenv("RTAMD_BLOCKS_PER_CU")) { int v = atoi(s); if (v > 0 && v <= 8) c.blocksPerCU = v; }
+    if (const char* s = getenv("RTAMD_REFILL_BELOW")) { int v = atoi(s); if (v >= 1 && v <= 64) c.refillBelow = v; }
+    if (const char* s = getenv("RTAMD_NODE_MIN")) { int v = atoi(s); if (v >= 1 && v <= 64) c.nodeMin = v; }
+    return c;
 }
 
 inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs& a, hipStream_t stream) {
@@ -618,36 +656,31 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
         numCU = prop.multiProcessorCount;
     }
-    int blocksPerCU = 4;
-    if (const char* s = getenv("RTAMD_BLOCKS_PER_CU")) { int v = atoi(s); if (v > 0 && v <= 8) blocksPerCU = v; }
-    int refillBelow = 40;
-    if (const char* s = getenv("RTAMD_REFILL_BELOW")) { int v = atoi(s); if (v >= 1 && v <= 64) refillBelow = v; }
+    const FastLaunchConfig cfg = fastLaunchConfig();
     long long wavesNeeded = ((long long)fs.hSuper.size() * 1024 + 63) / 64;
     long long blocksNeeded = (wavesNeeded + 3) / 4;
-    int grid = numCU * blocksPerCU;
+    int grid = numCU * cfg.blocksPerCU;
     if (blocksNeeded < grid) grid = (int)blocksNeeded;
     if (grid < 1) grid = 1;
-    size_t lanes = (size_t)grid * kBlockThreads;
-    if ((e = fs.overflow.ensure(lanes * (size_t)(kMaxStack - kLdsStack))) != hipSuccess) return e;
 
     FastScene sc;
-    sc.tlasNodes = fs.tlasNodes.p; sc.blasNodes = fs.blasNodes.p; sc.inst = fs.inst.p; sc.shade = fs.shade.p;
+    sc.nodes = fs.nodes.p; sc.inst = fs.inst.p; sc.shade = fs.shade.p;
     sc.tris = fs.tris.p; sc.nrms = fs.nrms.p; sc.superTiles = fs.superTiles.p; sc.nSuperTiles = (int)fs.hSuper.size();
-    sc.tlasRoot = 0; sc.overflow = fs.overflow.p; sc.overflowStride = (int)lanes;
+    sc.tlasRoot = fs.tlasRoot;
 
     if (a.mode == RTAMD_MODE_PT && (a.outIds || a.outT)) {
         // identity of the un-jittered primary hit: a separate, uncounted pass
         RenderArgs ids = a;
         ids.outRgba = nullptr; ids.accum = nullptr; ids.spp = 1;
-        hipLaunchKernelGGL(kFast<kModePrimary>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, ids, refillBelow);
+        hipLaunchKernelGGL(kFast<kModePrimary>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, ids, cfg.refillBelow, cfg.nodeMin);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         // the work-queue head and ray counter are shared: reset them between the passes
         if ((e = hipMemsetAsync(a.rayCount, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
     }
     if (a.mode == RTAMD_MODE_PT)
-        hipLaunchKernelGGL(kFast<kModePt>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, refillBelow);
+        hipLaunchKernelGGL(kFast<kModePt>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin);
     else
-        hipLaunchKernelGGL(kFast<kModeRef>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, refillBelow);
+        hipLaunchKernelGGL(kFast<kModeRef>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin);
     return hipGetLastError();
 }
 

@@ -85,6 +85,7 @@ struct rtamd_ctx {
     DevBuf<unsigned long long> rayCount;  // [0] rays, [1] work-queue head
     DevBuf<int32_t> errorFlag;
 
+    bool fastStackTooSmall = false;   // set when a ray outgrew the production kernel's LDS stack
     float lastKernelMs = 0.f;
     uint64_t lastRays = 0;
 };
@@ -248,6 +249,7 @@ int rtamd_scene_upload(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas, cons
         }
     }
     c->nBlas = nBlas;
+    c->fastStackTooSmall = false;
     c->hBlasOffsets.assign(blasOffsets, blasOffsets + nBlas);
     c->hTriOffsets.assign(triOffsets, triOffsets + nBlas);
     c->hVtxOffsets.assign(vtxOffsets, vtxOffsets + nBlas);
@@ -374,9 +376,6 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
         }
         a.accum = c->accum.p;
     }
-    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(rt::DevCounters), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->rayCount.p, 0, 2 * sizeof(unsigned long long), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->errorFlag.p, 0, sizeof(int32_t), c->stream));
     a.counters = wantCounters ? c->counters.p : nullptr;
     a.rayCount = c->rayCount.p;
     a.errorFlag = c->errorFlag.p;
@@ -384,34 +383,50 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
     rt::Sky sky;
     sky.texels = c->sky.p; sky.w = c->skyW; sky.h = c->skyH;
 
-    HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
-    if (a.tileW > 0 && a.tileH > 0) {
-        if (faithful) {
-            rt::RefScene sc;
-            sc.tlas = c->tlas.p; sc.blasOffsets = c->blasOffsets.p; sc.blas = c->blas.p; sc.vtxOffsets = c->vtxOffsets.p;
-            sc.verts = c->verts.p; sc.triOffsets = c->triOffsets.p; sc.tris = c->tris.p; sc.objects = c->objects.p;
-            dim3 grid((width + 7) / 8, (height + 7) / 8);
-            hipLaunchKernelGGL(rt::kFaithful, grid, dim3(64), 0, c->stream, sc, sky, a);
-        } else {
-            hipError_t le = rt::launchFast(c->fast, sky, a, c->stream);
-            if (le != hipSuccess) return failHip(c, le, "fast kernel launch");
-        }
-        HIP_TRY(c, hipGetLastError());
-    }
-    HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
-
-    if (out_rgba && !rgbaDev) HIP_TRY(c, hipMemcpyAsync(out_rgba, c->outRgba.p, npix * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    if (out_prim_id && !idsDev) HIP_TRY(c, hipMemcpyAsync(out_prim_id, c->outIds.p, npix * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (e.out_t && !tDev) HIP_TRY(c, hipMemcpyAsync(e.out_t, c->outT.p, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     rt::DevCounters hc;
     unsigned long long hr[2] = {0, 0};
     int32_t herr = 0;
-    HIP_TRY(c, hipMemcpyAsync(&hc, c->counters.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(hr, c->rayCount.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&herr, c->errorFlag.p, sizeof(herr), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&ms, c->evStart, c->evStop));
+    if (c->fastStackTooSmall) faithful = true;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(rt::DevCounters), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->rayCount.p, 0, 2 * sizeof(unsigned long long), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->errorFlag.p, 0, sizeof(int32_t), c->stream));
+        HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
+        if (a.tileW > 0 && a.tileH > 0) {
+            if (faithful) {
+                rt::RefScene sc;
+                sc.tlas = c->tlas.p; sc.blasOffsets = c->blasOffsets.p; sc.blas = c->blas.p; sc.vtxOffsets = c->vtxOffsets.p;
+                sc.verts = c->verts.p; sc.triOffsets = c->triOffsets.p; sc.tris = c->tris.p; sc.objects = c->objects.p;
+                dim3 grid((width + 7) / 8, (height + 7) / 8);
+                hipLaunchKernelGGL(rt::kFaithful, grid, dim3(64), 0, c->stream, sc, sky, a);
+            } else {
+                hipError_t le = rt::launchFast(c->fast, sky, a, c->stream);
+                if (le != hipSuccess) return failHip(c, le, "fast kernel launch");
+            }
+            HIP_TRY(c, hipGetLastError());
+        }
+        HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&hc, c->counters.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(hr, c->rayCount.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&herr, c->errorFlag.p, sizeof(herr), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->evStart, c->evStop));
+        if (!faithful && (herr & 2)) {
+            // a ray needed more stack than the production kernel keeps in LDS: this scene is
+            // rendered by the reference-order kernel from now on (its stacks have the
+            // reference's own capacity)
+            c->fastStackTooSmall = true;
+            if (a.accum) return fail(c, RTAMD_ERR_STACK_OVERFLOW, "traversal stack overflow while accumulating: reset the accumulation and render again");
+            faithful = true;
+            continue;
+        }
+        break;
+    }
+    if (out_rgba && !rgbaDev) HIP_TRY(c, hipMemcpyAsync(out_rgba, c->outRgba.p, npix * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (out_prim_id && !idsDev) HIP_TRY(c, hipMemcpyAsync(out_prim_id, c->outIds.p, npix * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (e.out_t && !tDev) HIP_TRY(c, hipMemcpyAsync(e.out_t, c->outT.p, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->lastKernelMs = ms;
     c->lastRays = hr[0];
     if (wantCounters) {
@@ -419,7 +434,7 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
         oc->rays = hc.rays; oc->nodes = hc.nodes; oc->tris = hc.tris; oc->instances = hc.instances; oc->hits = hc.hits;
         oc->max_blas_stack = hc.maxBlasStack; oc->max_tlas_stack = hc.maxTlasStack; oc->reserved = hc.overflow;
     }
-    if (herr) return fail(c, RTAMD_ERR_STACK_OVERFLOW, "traversal stack overflow (scene deeper than the shader's stacks allow)");
+    if (herr & 1) return fail(c, RTAMD_ERR_STACK_OVERFLOW, "traversal stack overflow (scene deeper than the shader's stacks allow)");
     return RTAMD_OK;
 }
 
