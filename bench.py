@@ -25,12 +25,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
 FP32_PEAK_TFLOPS = 157.3       # vector FP32, spec (packed FMA)
 
 
-def build_workload(name, width, height):
+def build_workload(name, width, height, tree=0):
     from raytracing_amd import scenes
     if name == "spheres":
-        return scenes.random_spheres(width, height), "random-spheres: floor + 484 instanced spheres (one 960-triangle BLAS)"
+        return scenes.random_spheres(width, height, tree=tree), "random-spheres: floor + 484 instanced spheres (one 960-triangle BLAS)"
     if name == "mesh":
-        return scenes.mesh_scene(width, height), "three procedural ~1M-triangle meshes + 4 quads"
+        return scenes.mesh_scene(width, height, tree=tree), "three procedural ~1M-triangle meshes + 4 quads"
     if name == "few":
         return scenes.few_spheres(width, height), "few-sphere plumbing scene"
     raise SystemExit(f"unknown workload {name}")
@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--tree", type=int, default=0, help="BLAS builder of the synthetic scene: 0 = reference median split, 1 = SAH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
     args = ap.parse_args()
@@ -84,7 +85,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    (buf, frame, sky), desc = build_workload(args.workload, args.width, args.height)
+    (buf, frame, sky), desc = build_workload(args.workload, args.width, args.height, args.tree)
     W, Hh = args.width, args.height
     rt = backend.RayTracingPass(local_rank)
     rt.SetScene(buf)

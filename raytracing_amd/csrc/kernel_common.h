@@ -40,10 +40,14 @@ struct RenderArgs {
     int32_t* outIds;        // may be null, 2 per pixel
     float* outT;            // may be null
     float4* accum;          // running sums (ACCUMULATE), may be null
-    float accumSamplesBefore;   // samples already in accum before this call
     DevCounters* counters;  // may be null
     unsigned long long* rayCount;   // always valid
     int32_t* errorFlag;     // always valid
+    // pixels the production kernel hands over to the reference-order kernel
+    uint32_t* redoMask;     // one bit per pixel
+    int32_t* redoList;      // pixel indices
+    int32_t* redoCount;
+    int32_t redoCap;
 };
 
 struct Ray { V3 origin, direction, invDir; };

@@ -179,15 +179,34 @@ __device__ __forceinline__ uint32_t waveMax(uint32_t v) {
 // One thread per pixel, 8x8 pixels per wave ([numthreads(8,8,1)], .compute:431).  Unlike
 // the reference dispatch (RayTracingPass.cs:101 launches width x height GROUPS) the grid
 // covers the image once.
-__global__ __launch_bounds__(64) void kFaithful(RefScene sc, Sky sky, RenderArgs a) {
+// With a pixel list (the pixels the production kernel handed over) the grid is
+// one-dimensional: in REF mode thread i renders pixel list[i]; in PT mode thread i traces
+// ONE sample, i % spp, of pixel list[i / spp] into sampleOut[i], and kSumListedSamples adds
+// a pixel's samples in sample order afterwards (the same order a single thread would use).
+__global__ __launch_bounds__(64) void kFaithful(RefScene sc, Sky sky, RenderArgs a, const int32_t* list, int listCount,
+                                                float4* sampleOut) {
     int x = blockIdx.x * 8 + (threadIdx.x & 7);
     int y = blockIdx.y * 8 + (threadIdx.x >> 3);
+    bool inside;
+    int sFirst = 0, sLast = a.spp;       // samples this thread traces
+    bool doPrimary = true;
+    int gi = 0;
+    if (list) {
+        gi = blockIdx.x * 64 + threadIdx.x;
+        const int per = a.mode == RTAMD_MODE_PT ? a.spp : 1;
+        inside = gi < listCount * per;
+        int p = inside ? list[gi / per] : 0;
+        x = p % a.width;
+        y = p / a.width;
+        if (a.mode == RTAMD_MODE_PT) { sFirst = gi % per; sLast = sFirst + 1; doPrimary = sFirst == 0; }
+    } else {
+        inside = x < a.width && y < a.height && pixelSelected(a, x, y);
+    }
     LocalCounters cnt = {0, 0, 0, 0, 0, 0, 0, 0};
     int32_t blasStack[kRefBlasStack];
-    bool inside = x < a.width && y < a.height && pixelSelected(a, x, y);
     if (inside) {
         size_t pix = (size_t)y * a.width + x;
-        if (a.mode == RTAMD_MODE_REF || a.outIds || a.outT) {
+        if (doPrimary && (a.mode == RTAMD_MODE_REF || a.outIds || a.outT)) {
             Ray cam = cameraRay(a.cb, pixelToNdc(x, a.cb.PixelOffset[0], a.width), pixelToNdc(y, a.cb.PixelOffset[1], a.height));
             LocalCounters side = {0, 0, 0, 0, 0, 0, 0, 0};
             LocalCounters& use = a.mode == RTAMD_MODE_REF ? cnt : side;
@@ -214,7 +233,7 @@ __global__ __launch_bounds__(64) void kFaithful(RefScene sc, Sky sky, RenderArgs
         }
         if (a.mode == RTAMD_MODE_PT) {
             V3 sum = v3(0, 0, 0);
-            for (int s = 0; s < a.spp; s++) {
+            for (int s = sFirst; s < sLast; s++) {
                 uint32_t key = rngKey(a.seedHi, a.seedLo, (uint32_t)pix, (uint32_t)(a.sampleOffset + s));
                 float jx = a.cb.PixelOffset[0], jy = a.cb.PixelOffset[1];
                 if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
@@ -232,7 +251,8 @@ __global__ __launch_bounds__(64) void kFaithful(RefScene sc, Sky sky, RenderArgs
                 }
                 sum = sum + L;
             }
-            writePathPixel(a, pix, sum);
+            if (sampleOut) sampleOut[gi] = make_float4(sum.x, sum.y, sum.z, 0.f);
+            else writePathPixel(a, pix, sum);
         }
     }
     // per-wave reduction of the counters, one atomic per wave and counter
@@ -254,6 +274,18 @@ __global__ __launch_bounds__(64) void kFaithful(RefScene sc, Sky sky, RenderArgs
         }
         if (ovf) atomicOr(a.errorFlag, 1);
     }
+}
+
+// Adds the spp samples of every listed pixel in sample order and writes the pixel.
+__global__ void kSumListedSamples(RenderArgs a, const int32_t* list, int listCount, const float4* samples) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= listCount) return;
+    V3 sum = v3(0, 0, 0);
+    for (int s = 0; s < a.spp; s++) {
+        float4 L = samples[(size_t)i * a.spp + s];
+        sum = sum + v3(L.x, L.y, L.z);
+    }
+    writePathPixel(a, (size_t)list[i], sum);
 }
 
 }  // namespace rt

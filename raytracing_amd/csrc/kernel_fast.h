@@ -9,18 +9,22 @@
 //   * triangles and instances are stored in the order the reference's depth-first walk
 //     would reach them, so "reached first" is "smaller index" and ties are broken by
 //     index, independent of the traversal order used here;
-//   * box tests of internal nodes only prune by distance, so nodes are visited nearest
-//     first; the reference's 4-triangle leaf NODES are folded into their parent, but each
-//     triangle keeps its leaf-slot box and is tested only if the reference's slab test
-//     (:233-263) of that box passes with the distance on entry to the leaf — a ray lying
-//     exactly in a box face makes that test fail (0 * inf = NaN is ignored by min/max),
-//     and the reference then never sees the triangle.
+//   * each triangle (instance) keeps the box of its leaf slot in the caller's tree and is
+//     tested (entered) only if the reference's slab test (:233-263) of that box passes;
+//   * the hierarchy above the primitives is rebuilt at upload (wide_bvh.h): every inner
+//     box is a union of those leaf-slot boxes, so inner boxes only prune by distance and
+//     nodes can be visited nearest first;
+//   * the one case where the caller's own inner boxes decide a hit — a ray with a zero
+//     direction component lying exactly in a box face (0 * inf = NaN is ignored by min/max,
+//     the box is missed and with it everything below) — is detected per ray segment, and the
+//     pixel is handed to the reference-order kernel.
 //
 // Layout (arrays 128-byte aligned in HBM; a lane's node is exactly one 128-byte line):
 //   WNode  128 B  lx,hx,ly,hy,lz,hz (float4 = the four children), child[4], pad;
 //                 BLAS nodes first, the TLAS nodes appended behind them
-//   FTri    64 B  (lo.xyz,hi.x)(hi.yz,index,v0.x)(v0.yz,e1.xy)(e1.z,e2.xyz) — visiting order
-//   FNrm    48 B  n0,n1,n2                                   — read once per closest hit
+//   FTri    64 B  (lo.xyz,hi.x)(hi.yz,rank,v0.x)(v0.yz,e1.xy)(e1.z,e2.xyz) — leaf order of the new tree;
+//                 rank = position in the reference's visiting order
+//   FNrm    48 B  n0,n1,n2, indexed by rank                  — read once per closest hit
 //   FInst   64 B  three rows of WorldToLocal, BLAS root, original object index
 //   FShade  96 B  three rows of LocalToWorld, albedo, specular, emission
 #pragma once
@@ -32,6 +36,7 @@
 #include <vector>
 
 #include "kernel_common.h"
+#include "wide_bvh.h"
 
 namespace rt {
 
@@ -55,7 +60,8 @@ struct FastScene {
     const FInst* inst;
     const FShade* shade;
     const FTri* tris;
-    const FNrm* nrms;
+    const FNrm* nrms;            // by triangle rank
+    const int32_t* triOrig;      // by triangle rank: the caller's triangle index
     const int32_t* superTiles;   // ids of the 32x32 pixel tiles this launch owns
     int32_t nSuperTiles;
     int32_t tlasRoot;            // index of the TLAS root in nodes
@@ -88,6 +94,7 @@ struct FastSceneHost {
     DBuf<FShade> shade;
     DBuf<FTri> tris;
     DBuf<FNrm> nrms;
+    DBuf<int32_t> triOrig;
     DBuf<int32_t> superTiles;
     DBuf<unsigned long long> stats;
     std::vector<int32_t> blasRoot;     // wide-node index of each BLAS root
@@ -98,47 +105,60 @@ struct FastSceneHost {
     std::vector<int32_t> hSuper;
     int nInst = 0;
     int tlasRoot = 0;
+    int maxDepth = 0;
 
     void release() {
-        nodes.release(); inst.release(); shade.release(); tris.release(); nrms.release(); superTiles.release();
+        nodes.release(); inst.release(); shade.release(); tris.release(); nrms.release(); triOrig.release();
+        superTiles.release(); stats.release();
     }
 
-    static void setChildBox(WNode& w, int slot, const rtamd_node& n, int i) {
-        (&w.lx.x)[slot] = n.Lx[i]; (&w.hx.x)[slot] = n.Hx[i];
-        (&w.ly.x)[slot] = n.Ly[i]; (&w.hy.x)[slot] = n.Hy[i];
-        (&w.lz.x)[slot] = n.Lz[i]; (&w.hz.x)[slot] = n.Hz[i];
-    }
-    // An empty slot gets lo = hi = +inf on every axis: whatever the ray, its entry distance
-    // comes out as +inf (or the slab test fails), which the kernel treats as a miss, so the
-    // child word of an empty slot is never looked at.
-    static void setEmptyBox(WNode& w, int slot) {
-        const float inf = __builtin_inff();
-        (&w.lx.x)[slot] = (&w.ly.x)[slot] = (&w.lz.x)[slot] = inf;
-        (&w.hx.x)[slot] = (&w.hy.x)[slot] = (&w.hz.x)[slot] = inf;
+    // Append the nodes of a built tree to hNodes.  leafCode(start, count) encodes a leaf.
+    template <typename LeafCode>
+    int appendTree(const WideTree& t, LeafCode leafCode) {
+        const int base = (int)hNodes.size();
+        for (const WideTree::Node& n : t.nodes) {
+            WNode w;
+            std::memset(&w, 0, sizeof(w));
+            int32_t ch[4];
+            for (int s = 0; s < 4; s++) {
+                (&w.lx.x)[s] = n.lo[s][0]; (&w.hx.x)[s] = n.hi[s][0];
+                (&w.ly.x)[s] = n.lo[s][1]; (&w.hy.x)[s] = n.hi[s][1];
+                (&w.lz.x)[s] = n.lo[s][2]; (&w.hz.x)[s] = n.hi[s][2];
+                if (n.child[s] == widebvh::kEmpty) ch[s] = kEmptyChild;     // box is all +inf: never entered
+                else if (n.child[s] >= 0) ch[s] = base + n.child[s];
+                else {
+                    uint32_t code = (uint32_t)~n.child[s];
+                    ch[s] = leafCode((int)(code >> 3), (int)(code & 7u));
+                }
+            }
+            w.child = make_int4(ch[0], ch[1], ch[2], ch[3]);
+            hNodes.push_back(w);
+        }
+        return base;
     }
 
-    // Re-pack every BLAS.  Inputs were validated by the caller (indices in range, every
-    // node reachable at most once).
+    // Re-build every BLAS.  Inputs were validated by the caller (indices in range, every
+    // node reachable at most once).  From the caller's tree come, per triangle, its leaf-slot
+    // box and its rank in the reference's visiting order (children pushed 0..3, popped last
+    // first, leaf slots 0..3: RayTracingShader.compute:293-345); the hierarchy itself is new.
     hipError_t buildBottom(const int32_t* blasOffsets, const rtamd_node* blas, const int32_t* nodeCount,
                            const int32_t* vtxOffsets, const rtamd_vertex* verts, const int32_t* triOffsets,
                            const rtamd_int3* tris_, const int32_t* triCount, int nBlas, hipStream_t stream,
                            std::string& err) {
-        (void)triCount;
-        std::vector<WNode>& wn = hNodes;
-        wn.clear();
-        std::vector<FTri> ft;
-        std::vector<FNrm> fn;
+        (void)triCount; (void)nodeCount;
+        hNodes.clear();
+        std::vector<FTri> ft;          // in leaf order of the new trees
+        std::vector<FNrm> fn;          // by global rank
+        std::vector<int32_t> orig;     // by global rank: the caller's triangle index
         blasRoot.assign(nBlas, 0);
+        maxDepth = 0;
         for (int b = 0; b < nBlas; b++) {
             const rtamd_node* nodes_ = blas + blasOffsets[b];
-            int nn = nodeCount[b];
             const rtamd_int3* tri = tris_ + triOffsets[b];
             const rtamd_vertex* vtx = verts + vtxOffsets[b];
-            size_t triBase = ft.size();
-            // pass 1: the reference's visiting order (children pushed 0..3, popped last first;
-            // leaf slots 0..3) gives every triangle its rank and every internal node its index
-            std::vector<int32_t> leafStart(nn, 0), leafCnt(nn, 0), wideIndex(nn, -1);
-            std::vector<int32_t> order;          // reference node indices of internal nodes, in visiting order
+            const size_t rankBase = fn.size();
+            std::vector<BuildBox> boxes;
+            std::vector<FTri> ranked;
             std::vector<int32_t> st;
             st.push_back(1);
             while (!st.empty()) {
@@ -146,122 +166,81 @@ struct FastSceneHost {
                 st.pop_back();
                 const rtamd_node& n = nodes_[ni];
                 if (n.Flags == 0) {
-                    wideIndex[ni] = (int32_t)(wn.size() + order.size());
-                    order.push_back(ni);
                     for (int i = 0; i < 4; i++) if (n.Data[i] != 0) st.push_back(n.Data[i]);
-                } else {
-                    leafStart[ni] = (int32_t)(ft.size() - triBase);
-                    for (int i = 0; i < 4; i++) {
-                        int t = n.Data[i];
-                        if (t == -1) continue;
-                        const float* p0 = vtx[tri[t].x].position;
-                        const float* p1 = vtx[tri[t].y].position;
-                        const float* p2 = vtx[tri[t].z].position;
-                        // e1 = v1 - v0, e2 = v2 - v0: the same binary32 subtractions Trisection does (:201-202)
-                        float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
-                        float e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
-                        float idx;
-                        std::memcpy(&idx, &t, 4);
-                        FTri f;
-                        f.a = make_float4(n.Lx[i], n.Ly[i], n.Lz[i], n.Hx[i]);
-                        f.b = make_float4(n.Hy[i], n.Hz[i], idx, p0[0]);
-                        f.c = make_float4(p0[1], p0[2], e1[0], e1[1]);
-                        f.d = make_float4(e1[2], e2[0], e2[1], e2[2]);
-                        ft.push_back(f);
-                        const float* n0 = vtx[tri[t].x].normal;
-                        const float* n1 = vtx[tri[t].y].normal;
-                        const float* n2 = vtx[tri[t].z].normal;
-                        FNrm g;
-                        g.a = make_float4(n0[0], n0[1], n0[2], n1[0]);
-                        g.b = make_float4(n1[1], n1[2], n2[0], n2[1]);
-                        g.c = make_float4(n2[2], 0.f, 0.f, 0.f);
-                        fn.push_back(g);
-                        leafCnt[ni]++;
-                    }
+                    continue;
                 }
-            }
-            if (ft.size() >= (1u << 28)) { err = "too many triangles for the leaf encoding"; return hipSuccess; }
-            auto leafCode = [&](int ni) -> int32_t {
-                if (leafCnt[ni] == 0) return kEmptyChild;
-                uint32_t start = (uint32_t)(triBase + leafStart[ni]);
-                return ~(int32_t)((start << 2) | (uint32_t)(leafCnt[ni] - 1));
-            };
-            if (nodes_[1].Flags != 0) {
-                // a tree whose root is itself a leaf node: wrap it so the kernel always starts at a node
-                WNode w;
-                std::memset(&w, 0, sizeof(w));
-                for (int s = 0; s < 4; s++) setEmptyBox(w, s);
-                const rtamd_node& n = nodes_[1];
-                float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
                 for (int i = 0; i < 4; i++) {
-                    if (n.Data[i] == -1) continue;
-                    lo[0] = std::fmin(lo[0], n.Lx[i]); lo[1] = std::fmin(lo[1], n.Ly[i]); lo[2] = std::fmin(lo[2], n.Lz[i]);
-                    hi[0] = std::fmax(hi[0], n.Hx[i]); hi[1] = std::fmax(hi[1], n.Hy[i]); hi[2] = std::fmax(hi[2], n.Hz[i]);
+                    int t = n.Data[i];
+                    if (t == -1) continue;
+                    const float* p0 = vtx[tri[t].x].position;
+                    const float* p1 = vtx[tri[t].y].position;
+                    const float* p2 = vtx[tri[t].z].position;
+                    // e1 = v1 - v0, e2 = v2 - v0: the same binary32 subtractions Trisection does (:201-202)
+                    float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+                    float e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+                    int32_t rank = (int32_t)(rankBase + ranked.size());
+                    float rk;
+                    std::memcpy(&rk, &rank, 4);
+                    FTri f;
+                    f.a = make_float4(n.Lx[i], n.Ly[i], n.Lz[i], n.Hx[i]);
+                    f.b = make_float4(n.Hy[i], n.Hz[i], rk, p0[0]);
+                    f.c = make_float4(p0[1], p0[2], e1[0], e1[1]);
+                    f.d = make_float4(e1[2], e2[0], e2[1], e2[2]);
+                    ranked.push_back(f);
+                    BuildBox bx = {{n.Lx[i], n.Ly[i], n.Lz[i]}, {n.Hx[i], n.Hy[i], n.Hz[i]}};
+                    boxes.push_back(bx);
+                    const float* n0 = vtx[tri[t].x].normal;
+                    const float* n1 = vtx[tri[t].y].normal;
+                    const float* n2 = vtx[tri[t].z].normal;
+                    FNrm g;
+                    g.a = make_float4(n0[0], n0[1], n0[2], n1[0]);
+                    g.b = make_float4(n1[1], n1[2], n2[0], n2[1]);
+                    g.c = make_float4(n2[2], 0.f, 0.f, 0.f);
+                    fn.push_back(g);
+                    orig.push_back(t);
                 }
-                int32_t c0 = leafCode(1);
-                if (c0 != kEmptyChild) { w.lx.x = lo[0]; w.ly.x = lo[1]; w.lz.x = lo[2]; w.hx.x = hi[0]; w.hy.x = hi[1]; w.hz.x = hi[2]; }
-                w.child = make_int4(c0, kEmptyChild, kEmptyChild, kEmptyChild);
-                blasRoot[b] = (int32_t)wn.size();
-                wn.push_back(w);
-                continue;
             }
-            blasRoot[b] = wideIndex[1];
-            // pass 2: emit the internal nodes in the same order
-            for (int ni : order) {
-                const rtamd_node& n = nodes_[ni];
-                WNode w;
-                std::memset(&w, 0, sizeof(w));
-                int32_t ch[4];
-                for (int i = 0; i < 4; i++) {
-                    int c = n.Data[i];
-                    if (c == 0) { ch[i] = kEmptyChild; setEmptyBox(w, i); continue; }
-                    setChildBox(w, i, n, i);
-                    ch[i] = nodes_[c].Flags == 0 ? wideIndex[c] : leafCode(c);
-                    if (ch[i] == kEmptyChild) setEmptyBox(w, i);
-                }
-                w.child = make_int4(ch[0], ch[1], ch[2], ch[3]);
-                wn.push_back(w);
-            }
+            if (fn.size() >= (1u << 28)) { err = "too many triangles for the leaf encoding"; return hipSuccess; }
+            WideTree tree;
+            buildWideTree(boxes.data(), (int)boxes.size(), 4, tree);
+            if (tree.depth > maxDepth) maxDepth = tree.depth;
+            const uint32_t triBase = (uint32_t)ft.size();
+            for (int32_t it : tree.order) ft.push_back(ranked[it]);
+            blasRoot[b] = appendTree(tree, [&](int start, int count) -> int32_t {
+                return ~(int32_t)(((triBase + (uint32_t)start) << 2) | (uint32_t)(count - 1));
+            });
         }
-        nBlasNodes = wn.size();
+        nBlasNodes = hNodes.size();
         hipError_t e;
         if ((e = tris.put(ft, stream)) != hipSuccess) return e;
         if ((e = nrms.put(fn, stream)) != hipSuccess) return e;
-        return hipStreamSynchronize(stream);   // ft / fn die with this scope; the nodes go up with the TLAS
+        if ((e = triOrig.put(orig, stream)) != hipSuccess) return e;
+        return hipStreamSynchronize(stream);   // ft / fn / orig die with this scope; the nodes go up with the TLAS
     }
 
-    // Re-pack the TLAS (node for node) behind the BLAS nodes, and the per-object data with
-    // instances in visiting order.
+    // Re-build the TLAS behind the BLAS nodes and the per-object data.  Instances are kept
+    // in the reference's visiting order (IntersectTLAS, .compute:355-381: inner children
+    // popped last first, leaf slots 0..3) and keep the box of their TLAS leaf slot.
     hipError_t buildTop(const rtamd_node* tlas, int nTlas, const rtamd_object_property* objects, int nObjects,
                         hipStream_t stream, std::string& err) {
-        (void)nObjects;
+        (void)nObjects; (void)nTlas;
         hNodes.resize(nBlasNodes);
         hInst.clear(); hShade.clear();
-        std::vector<int32_t> wideIndex(nTlas, -1), order, st;
+        std::vector<BuildBox> boxes;
+        std::vector<int32_t> st;
         st.push_back(1);
         while (!st.empty()) {
             int ni = st.back();
             st.pop_back();
-            wideIndex[ni] = (int32_t)(nBlasNodes + order.size());
-            order.push_back(ni);
             const rtamd_node& n = tlas[ni];
-            if (n.Flags == 0)
+            if (n.Flags == 0) {
                 for (int i = 0; i < 4; i++) if (n.Data[i] != 0) st.push_back(n.Data[i]);
-        }
-        tlasRoot = (int)nBlasNodes;
-        for (int ni : order) {
-            const rtamd_node& n = tlas[ni];
-            WNode w;
-            std::memset(&w, 0, sizeof(w));
-            int32_t ch[4];
+                continue;
+            }
             for (int i = 0; i < 4; i++) {
                 int d = n.Data[i];
-                bool valid = n.Flags == 0 ? d != 0 : d != -1;
-                if (!valid) { ch[i] = kEmptyChild; setEmptyBox(w, i); continue; }
-                setChildBox(w, i, n, i);
-                if (n.Flags == 0) { ch[i] = wideIndex[d]; continue; }
+                if (d == -1) continue;
                 const rtamd_object_property& o = objects[d];
-                uint32_t rank = (uint32_t)hInst.size();
                 FInst fi;
                 const float* m = o.WorldToLocal;
                 fi.r0 = make_float4(m[0], m[4], m[8], m[12]);
@@ -278,19 +257,26 @@ struct FastSceneHost {
                 fs.specular = make_float4(o.specular[0], o.specular[1], o.specular[2], o.specular[3]);
                 fs.emission = make_float4(o.emission[0], o.emission[1], o.emission[2], o.emission[3]);
                 hShade.push_back(fs);
-                ch[i] = ~(int32_t)(rank | kInstanceBit);
+                BuildBox bx = {{n.Lx[i], n.Ly[i], n.Lz[i]}, {n.Hx[i], n.Hy[i], n.Hz[i]}};
+                boxes.push_back(bx);
             }
-            w.child = make_int4(ch[0], ch[1], ch[2], ch[3]);
-            hNodes.push_back(w);
         }
         if (hInst.empty()) { err = "TLAS references no object"; return hipSuccess; }
         if (hInst.size() >= kInstanceBit) { err = "too many instances"; return hipSuccess; }
         nInst = (int)hInst.size();
+        WideTree tree;
+        buildWideTree(boxes.data(), nInst, 1, tree);
+        tlasRoot = appendTree(tree, [&](int start, int count) -> int32_t {
+            (void)count;   // one instance per leaf: the leaf's box is the instance's own TLAS slot box
+            return ~(int32_t)((uint32_t)tree.order[start] | kInstanceBit);
+        });
+        tlasDepth = tree.depth;
         hipError_t e;
         if ((e = nodes.put(hNodes, stream)) != hipSuccess) return e;
         if ((e = inst.put(hInst, stream)) != hipSuccess) return e;
         return shade.put(hShade, stream);
     }
+    int tlasDepth = 0;
 };
 
 // ------------------------------------------------------------------ kernel ---
@@ -306,7 +292,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct FastHit {
     float t, u, v;
-    int32_t inst, tri;   // instance rank, absolute triangle slot
+    int32_t inst, tri;   // instance rank, triangle rank (positions in the reference's visiting order)
 };
 
 // mul(M, float4(v,1)).xyz and mul(M, float4(v,0)).xyz for a matrix stored as three rows.
@@ -356,6 +342,12 @@ __device__ __forceinline__ void cswap(float& da, int32_t& ca, float& db, int32_t
     da = td; db = tb; ca = tc; cb = te;
 }
 
+// A reciprocal direction component that is not finite (the direction component is 0, or
+// so small that 1/d overflows) can turn a slab product into 0 * inf = NaN.
+__device__ __forceinline__ bool rayDegenerate(const Ray& r) {
+    return !(__builtin_fabsf(r.invDir.x) < RT_INF) || !(__builtin_fabsf(r.invDir.y) < RT_INF) || !(__builtin_fabsf(r.invDir.z) < RT_INF);
+}
+
 struct Surf { V3 position, normal, albedo, specular, emission; int32_t object, triangle; };
 
 // Position, shading normal and material of the closest hit (.compute:329-339).
@@ -374,7 +366,7 @@ __device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world
     s.specular = v3(fs.specular.x, fs.specular.y, fs.specular.z);
     s.emission = v3(fs.emission.x, fs.emission.y, fs.emission.z);
     s.object = fi.object;
-    s.triangle = __float_as_int(sc.tris[h.tri].b.z);
+    s.triangle = sc.triOrig[h.tri];
     return s;
 }
 
@@ -387,9 +379,10 @@ __device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world
 //     least `nodeMin` lanes still have inner nodes to test, then all leaves are handled
 //     together (a per-round vote between node / triangle / instance steps measured 8 % slower);
 //   * the wave draws pixels from one global counter, 8x8 pixel tiles first.
-// The traversal stack lives in LDS ([entry][thread], one bank per lane).  A ray that
-// needs more than kLdsStack entries raises the error flag; the host then repeats the frame
-// with the reference-order kernel, whose stacks have the reference's own capacity.
+// The traversal stack lives in LDS ([entry][thread], one bank per lane).  A pixel with a ray
+// that needs more than kLdsStack entries, or with a ray that could meet 0 * inf in a slab
+// test, is dropped unfinished and listed for the reference-order kernel, which the host runs
+// over that list afterwards.
 // STATS = true builds a diagnostic variant that also counts, per phase, how often the wave
 // executed it and with how many active lanes (written to `stats`, 16 counters).
 template <int MODE, bool STATS>
@@ -425,16 +418,15 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
     FastHit best;
     best.t = RT_INF; best.u = best.v = 0; best.inst = -1; best.tri = -1;
     int32_t node = 0;
-    int sp = 0, spMax = 0;
+    int sp = 0;
     int instSp = -1;          // stack height on entering the current instance, -1 outside
     int32_t curInst = -1;
-    uint32_t rays = 0;
+    uint32_t rays = 0, pixRays = 0;   // ray segments of finished pixels / of the current pixel
 
 #define RT_PUSH(v)                                                        \
     do {                                                                  \
         ldsStack[sp < kLdsStack ? sp : kLdsStack - 1][tid] = (v);         \
         sp++;                                                             \
-        spMax = sp > spMax ? sp : spMax;                                  \
     } while (0)
     // next stack entry; leaving an instance restores the world-space ray (.compute:377 returns)
 #define RT_POP()                                                          \
@@ -442,6 +434,20 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
         if (sp == instSp) { cur = world; curInst = -1; instSp = -1; }     \
         if (sp == 0) { trav = false; node = 0; }                          \
         else { sp--; node = ldsStack[sp < kLdsStack ? sp : kLdsStack - 1][tid]; } \
+    } while (0)
+
+    // Hand the current pixel to the reference-order kernel: mark it, list it once, drop it.
+#define RT_REDO()                                                                   \
+    do {                                                                            \
+        const uint32_t p_ = (uint32_t)py * (uint32_t)a.width + (uint32_t)px;        \
+        const uint32_t bit_ = 1u << (p_ & 31u);                                     \
+        const uint32_t old_ = atomicOr(a.redoMask + (p_ >> 5), bit_);               \
+        if (!(old_ & bit_)) {                                                       \
+            const int i_ = atomicAdd(a.redoCount, 1);                               \
+            if (i_ < a.redoCap) a.redoList[i_] = (int32_t)p_;                       \
+            else atomicOr(a.errorFlag, 4);                                          \
+        }                                                                           \
+        pixelActive = false; pathActive = false; trav = false; pixRays = 0;         \
     } while (0)
 
     for (;;) {
@@ -502,6 +508,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
             if (!haveRay && pixelActive && sample >= (MODE == kModePt ? a.spp : 1)) {
                 if (MODE == kModePt) writePathPixel(a, (size_t)py * a.width + px, sum);
                 pixelActive = false;
+                rays += pixRays;
+                pixRays = 0;
             }
             // fetch pixels for lanes that have none: one atomic per wave and round, shared by ballot
             for (;;) {
@@ -524,7 +532,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                         int x = sx * 32 + (t8 & 3) * 8 + (p8 & 7);
                         int y = sy * 32 + (t8 >> 2) * 8 + (p8 >> 3);
                         if (x < a.width && y < a.height && x >= a.tileX && y >= a.tileY && x < a.tileX + a.tileW && y < a.tileY + a.tileH) {
-                            px = x; py = y; pixelActive = true; sample = 0; sum = v3(0, 0, 0);
+                            const uint32_t p = (uint32_t)y * (uint32_t)a.width + (uint32_t)x;
+                            // (a pixel an earlier pass of this render already handed over is skipped)
+                            if (!((a.redoMask[p >> 5] >> (p & 31u)) & 1u)) { px = x; py = y; pixelActive = true; sample = 0; sum = v3(0, 0, 0); pixRays = 0; }
                         }
                     }
                 }
@@ -546,7 +556,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                 best.t = RT_INF; best.inst = -1; best.tri = -1;
                 node = sc.tlasRoot; sp = 0; instSp = -1; curInst = -1;
                 trav = true;
-                rays++;
+                pixRays++;
+                if (rayDegenerate(next)) RT_REDO();
             }
         }
         if (__ballot(trav) == 0ull) break;   // nobody got a ray: every lane is out of work
@@ -582,6 +593,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                     if (nh > 1) RT_PUSH(c1);
                     if (nh > 0) node = c0;
                     else RT_POP();
+                    // a ray that needs more stack than LDS holds goes to the reference-order kernel
+                    if (sp > kLdsStack) RT_REDO();
                 }
             }
             // B2: leaves
@@ -598,6 +611,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                     instSp = sp;
                     node = fi.root;
                     curInst = rank;
+                    if (rayDegenerate(cur)) RT_REDO();
                 } else {
                     const uint32_t start = code >> 2;
                     const int cnt = (int)(code & 3u) + 1;
@@ -620,7 +634,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                         const float4 B = tp[1], C = tp[2], D = tp[3];
                         float t, u, v;
                         if (trisect(cur.origin, cur.direction, v3(B.w, C.x, C.y), v3(C.z, C.w, D.x), v3(D.y, D.z, D.w), t, u, v)) {
-                            const int32_t ti = (int32_t)(start + k);
+                            const int32_t ti = __float_as_int(B.z);
                             const bool closer = t < best.t;
                             const bool tie = t == best.t && (curInst < best.inst || (curInst == best.inst && ti < best.tri));
                             if (closer || tie) { best.t = t; best.u = u; best.v = v; best.inst = curInst; best.tri = ti; }
@@ -640,8 +654,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
     }
 #undef RT_PUSH
 #undef RT_POP
+#undef RT_REDO
 #undef RT_STAT
-    if (spMax > kLdsStack) atomicOr(a.errorFlag, 2);
     if (STATS && lane == 0)
         for (int i = 0; i < 16; i++) if (st_[i]) atomicAdd(stats + i, st_[i]);
     unsigned long long r = rays;
@@ -695,7 +709,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
 
     FastScene sc;
     sc.nodes = fs.nodes.p; sc.inst = fs.inst.p; sc.shade = fs.shade.p;
-    sc.tris = fs.tris.p; sc.nrms = fs.nrms.p; sc.superTiles = fs.superTiles.p; sc.nSuperTiles = (int)fs.hSuper.size();
+    sc.tris = fs.tris.p; sc.nrms = fs.nrms.p; sc.triOrig = fs.triOrig.p; sc.superTiles = fs.superTiles.p; sc.nSuperTiles = (int)fs.hSuper.size();
     sc.tlasRoot = fs.tlasRoot;
 
     if (a.mode == RTAMD_MODE_PT && (a.outIds || a.outT)) {

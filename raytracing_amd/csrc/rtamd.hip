@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -85,7 +86,10 @@ struct rtamd_ctx {
     DevBuf<unsigned long long> rayCount;  // [0] rays, [1] work-queue head
     DevBuf<int32_t> errorFlag;
 
-    bool fastStackTooSmall = false;   // set when a ray outgrew the production kernel's LDS stack
+    DevBuf<uint32_t> redoMask;            // pixels handed from the production kernel to the reference-order kernel
+    DevBuf<int32_t> redoList, redoCount;
+    DevBuf<float4> redoSamples;
+    int32_t lastRedoPixels = 0;
     float lastKernelMs = 0.f;
     uint64_t lastRays = 0;
 };
@@ -168,7 +172,7 @@ int rtamd_ctx_create(int device_ordinal, rtamd_ctx** out_ctx) {
     c->device = device_ordinal;
     if ((e = hipSetDevice(device_ordinal)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess ||
-        (e = c->counters.alloc(1)) != hipSuccess || (e = c->rayCount.alloc(2)) != hipSuccess || (e = c->errorFlag.alloc(1)) != hipSuccess) {
+        (e = c->counters.alloc(1)) != hipSuccess || (e = c->rayCount.alloc(2)) != hipSuccess || (e = c->errorFlag.alloc(1)) != hipSuccess || (e = c->redoCount.alloc(1)) != hipSuccess) {
         int rc = failHip(nullptr, e, "context creation");
         rtamd_ctx_destroy(c);
         return rc;
@@ -185,7 +189,7 @@ int rtamd_ctx_destroy(rtamd_ctx* c) {
     c->tlas.release(); c->blas.release(); c->blasOffsets.release(); c->vtxOffsets.release(); c->triOffsets.release();
     c->verts.release(); c->tris.release(); c->objects.release(); c->sky.release(); c->accum.release();
     c->outRgba.release(); c->outIds.release(); c->outT.release(); c->counters.release(); c->rayCount.release();
-    c->errorFlag.release();
+    c->errorFlag.release(); c->redoMask.release(); c->redoList.release(); c->redoCount.release(); c->redoSamples.release();
     c->fast.release();
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
@@ -249,7 +253,6 @@ int rtamd_scene_upload(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas, cons
         }
     }
     c->nBlas = nBlas;
-    c->fastStackTooSmall = false;
     c->hBlasOffsets.assign(blasOffsets, blasOffsets + nBlas);
     c->hTriOffsets.assign(triOffsets, triOffsets + nBlas);
     c->hVtxOffsets.assign(vtxOffsets, vtxOffsets + nBlas);
@@ -385,44 +388,67 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
 
     rt::DevCounters hc;
     unsigned long long hr[2] = {0, 0};
-    int32_t herr = 0;
+    int32_t herr = 0, redo = 0;
     float ms = 0.f;
-    if (c->fastStackTooSmall) faithful = true;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(rt::DevCounters), c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->rayCount.p, 0, 2 * sizeof(unsigned long long), c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->errorFlag.p, 0, sizeof(int32_t), c->stream));
-        HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
-        if (a.tileW > 0 && a.tileH > 0) {
-            if (faithful) {
-                rt::RefScene sc;
-                sc.tlas = c->tlas.p; sc.blasOffsets = c->blasOffsets.p; sc.blas = c->blas.p; sc.vtxOffsets = c->vtxOffsets.p;
-                sc.verts = c->verts.p; sc.triOffsets = c->triOffsets.p; sc.tris = c->tris.p; sc.objects = c->objects.p;
-                dim3 grid((width + 7) / 8, (height + 7) / 8);
-                hipLaunchKernelGGL(rt::kFaithful, grid, dim3(64), 0, c->stream, sc, sky, a);
-            } else {
-                hipError_t le = rt::launchFast(c->fast, sky, a, c->stream);
-                if (le != hipSuccess) return failHip(c, le, "fast kernel launch");
-            }
-            HIP_TRY(c, hipGetLastError());
+    const size_t maskWords = (npix + 31) / 32;
+    HIP_TRY(c, c->redoMask.alloc(maskWords));
+    HIP_TRY(c, c->redoList.alloc(npix));
+    HIP_TRY(c, hipMemsetAsync(c->redoMask.p, 0, maskWords * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->redoCount.p, 0, sizeof(int32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(rt::DevCounters), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->rayCount.p, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->errorFlag.p, 0, sizeof(int32_t), c->stream));
+    a.redoMask = c->redoMask.p; a.redoList = c->redoList.p; a.redoCount = c->redoCount.p; a.redoCap = (int32_t)npix;
+    rt::RefScene rsc;
+    rsc.tlas = c->tlas.p; rsc.blasOffsets = c->blasOffsets.p; rsc.blas = c->blas.p; rsc.vtxOffsets = c->vtxOffsets.p;
+    rsc.verts = c->verts.p; rsc.triOffsets = c->triOffsets.p; rsc.tris = c->tris.p; rsc.objects = c->objects.p;
+    HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
+    if (a.tileW > 0 && a.tileH > 0) {
+        if (faithful) {
+            dim3 grid((width + 7) / 8, (height + 7) / 8);
+            hipLaunchKernelGGL(rt::kFaithful, grid, dim3(64), 0, c->stream, rsc, sky, a, (const int32_t*)nullptr, 0, (float4*)nullptr);
+        } else {
+            hipError_t le = rt::launchFast(c->fast, sky, a, c->stream);
+            if (le != hipSuccess) return failHip(c, le, "fast kernel launch");
         }
-        HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(&hc, c->counters.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(hr, c->rayCount.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(&herr, c->errorFlag.p, sizeof(herr), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->evStart, c->evStop));
-        if (!faithful && (herr & 2)) {
-            // a ray needed more stack than the production kernel keeps in LDS: this scene is
-            // rendered by the reference-order kernel from now on (its stacks have the
-            // reference's own capacity)
-            c->fastStackTooSmall = true;
-            if (a.accum) return fail(c, RTAMD_ERR_STACK_OVERFLOW, "traversal stack overflow while accumulating: reset the accumulation and render again");
-            faithful = true;
-            continue;
-        }
-        break;
+        HIP_TRY(c, hipGetLastError());
     }
+    HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&redo, c->redoCount.p, sizeof(redo), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->evStart, c->evStop));
+    if (redo > 0) {
+        // pixels the production kernel handed over (a ray with a zero direction component, or
+        // a stack deeper than its LDS stack): the reference-order kernel renders exactly those
+        if (redo > (int32_t)npix) redo = (int32_t)npix;
+        float ms2 = 0.f;
+        HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
+        if (a.mode == RTAMD_MODE_PT) {
+            // one thread per (pixel, sample), then an in-order sum per pixel
+            const size_t n = (size_t)redo * (size_t)a.spp;
+            HIP_TRY(c, c->redoSamples.alloc(n));
+            hipLaunchKernelGGL(rt::kFaithful, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, rsc, sky, a,
+                               (const int32_t*)c->redoList.p, redo, c->redoSamples.p);
+            HIP_TRY(c, hipGetLastError());
+            hipLaunchKernelGGL(rt::kSumListedSamples, dim3((redo + 63) / 64), dim3(64), 0, c->stream, a,
+                               (const int32_t*)c->redoList.p, redo, (const float4*)c->redoSamples.p);
+        } else {
+            hipLaunchKernelGGL(rt::kFaithful, dim3((redo + 63) / 64), dim3(64), 0, c->stream, rsc, sky, a,
+                               (const int32_t*)c->redoList.p, redo, (float4*)nullptr);
+        }
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipEventElapsedTime(&ms2, c->evStart, c->evStop));
+        ms += ms2;
+    }
+    c->lastRedoPixels = redo;
+    if (getenv("RTAMD_VERBOSE"))
+        fprintf(stderr, "[rtamd] render %dx%d mode %d: %.3f ms, %d pixels handed to the reference-order kernel; nodes %zu (BLAS %zu), depth BLAS %d TLAS %d, instances %d\n",
+                width, height, a.mode, ms, redo, c->fast.hNodes.size(), c->fast.nBlasNodes, c->fast.maxDepth, c->fast.tlasDepth, c->fast.nInst);
+    HIP_TRY(c, hipMemcpyAsync(&hc, c->counters.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hr, c->rayCount.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&herr, c->errorFlag.p, sizeof(herr), hipMemcpyDeviceToHost, c->stream));
     if (out_rgba && !rgbaDev) HIP_TRY(c, hipMemcpyAsync(out_rgba, c->outRgba.p, npix * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     if (out_prim_id && !idsDev) HIP_TRY(c, hipMemcpyAsync(out_prim_id, c->outIds.p, npix * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     if (e.out_t && !tDev) HIP_TRY(c, hipMemcpyAsync(e.out_t, c->outT.p, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));

@@ -1,0 +1,202 @@
+// 4-wide BVH construction for the GPU layout (host code, runs at scene upload).
+//
+// The library does not traverse the caller's trees in the production kernel: the
+// reference's median-split builder (Assets/Script/BVH/BoundingVolumeHierarchyBuilder.cs,
+// with its left-size miscount at :298) yields trees that cost several times more node
+// visits per ray than a surface-area-heuristic tree over the same primitives.  What must
+// be kept from the caller's tree is only what decides hits: each primitive's own leaf-slot
+// box and the order in which the reference would visit primitives (for ties).  Every
+// inner box built here is the union of the leaf-slot boxes below it, so a primitive whose
+// own box passes the reference's slab test also passes every box above it (the slab
+// arithmetic is monotone in the box bounds as long as no 0 * inf occurs; rays for which it
+// can occur are handed to the reference-order kernel).
+//
+// Builder: top-down binned SAH (32 bins, three axes) on box centroids; a node takes the
+// range, splits it, then keeps splitting the part with the largest area * count until it
+// has four parts (or every part fits a leaf).
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace rt {
+
+struct BuildBox { float lo[3], hi[3]; };
+
+struct WideTree {
+    struct Node { float lo[4][3], hi[4][3]; int32_t child[4]; };   // child: >= 0 node; < 0: ~((start << 3) | count); INT32_MIN empty
+    std::vector<Node> nodes;            // node 0 is the root
+    std::vector<int32_t> order;         // position in leaf order -> input item
+    int depth = 0;
+};
+
+namespace widebvh {
+
+constexpr int32_t kEmpty = INT32_MIN;
+constexpr int kBins = 32;
+
+struct Item { float c[3]; int32_t index; };
+
+inline float halfArea(const float lo[3], const float hi[3]) {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (!(dx >= 0) || !(dy >= 0) || !(dz >= 0)) return 0.f;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+struct Builder {
+    const BuildBox* boxes;
+    std::vector<Item> items;
+    WideTree* out;
+    int maxLeaf;
+
+    void bounds(int lo, int hi, float blo[3], float bhi[3]) const {
+        for (int k = 0; k < 3; k++) { blo[k] = __builtin_inff(); bhi[k] = -__builtin_inff(); }
+        for (int i = lo; i < hi; i++) {
+            const BuildBox& b = boxes[items[i].index];
+            for (int k = 0; k < 3; k++) { blo[k] = std::min(blo[k], b.lo[k]); bhi[k] = std::max(bhi[k], b.hi[k]); }
+        }
+    }
+
+    // split [lo,hi) in two; returns mid with lo < mid < hi
+    int split(int lo, int hi) {
+        const int n = hi - lo;
+        float clo[3], chi[3];
+        for (int k = 0; k < 3; k++) { clo[k] = __builtin_inff(); chi[k] = -__builtin_inff(); }
+        for (int i = lo; i < hi; i++)
+            for (int k = 0; k < 3; k++) { clo[k] = std::min(clo[k], items[i].c[k]); chi[k] = std::max(chi[k], items[i].c[k]); }
+        float bestCost = __builtin_inff();
+        int bestAxis = -1, bestBin = -1;
+        for (int axis = 0; axis < 3; axis++) {
+            if (!(chi[axis] > clo[axis])) continue;
+            const float scale = kBins / (chi[axis] - clo[axis]);
+            float blo[kBins][3], bhi[kBins][3];
+            int cnt[kBins];
+            for (int b = 0; b < kBins; b++) {
+                cnt[b] = 0;
+                for (int k = 0; k < 3; k++) { blo[b][k] = __builtin_inff(); bhi[b][k] = -__builtin_inff(); }
+            }
+            for (int i = lo; i < hi; i++) {
+                int b = (int)((items[i].c[axis] - clo[axis]) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                const BuildBox& bx = boxes[items[i].index];
+                for (int k = 0; k < 3; k++) { blo[b][k] = std::min(blo[b][k], bx.lo[k]); bhi[b][k] = std::max(bhi[b][k], bx.hi[k]); }
+                cnt[b]++;
+            }
+            float rArea[kBins];
+            int rCnt[kBins];
+            float alo[3], ahi[3];
+            for (int k = 0; k < 3; k++) { alo[k] = __builtin_inff(); ahi[k] = -__builtin_inff(); }
+            int c = 0;
+            for (int b = kBins - 1; b > 0; b--) {
+                for (int k = 0; k < 3; k++) { alo[k] = std::min(alo[k], blo[b][k]); ahi[k] = std::max(ahi[k], bhi[b][k]); }
+                c += cnt[b];
+                rArea[b] = halfArea(alo, ahi);
+                rCnt[b] = c;
+            }
+            for (int k = 0; k < 3; k++) { alo[k] = __builtin_inff(); ahi[k] = -__builtin_inff(); }
+            c = 0;
+            for (int b = 0; b < kBins - 1; b++) {
+                for (int k = 0; k < 3; k++) { alo[k] = std::min(alo[k], blo[b][k]); ahi[k] = std::max(ahi[k], bhi[b][k]); }
+                c += cnt[b];
+                if (c == 0 || rCnt[b + 1] == 0) continue;
+                // cost in leaf-sized groups: a leaf holds up to maxLeaf primitives
+                float cost = halfArea(alo, ahi) * (float)((c + maxLeaf - 1) / maxLeaf) +
+                             rArea[b + 1] * (float)((rCnt[b + 1] + maxLeaf - 1) / maxLeaf);
+                if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
+            }
+        }
+        if (bestAxis < 0) return lo + n / 2;     // all centroids coincide
+        const float cmin = clo[bestAxis];
+        const float scale = kBins / (chi[bestAxis] - clo[bestAxis]);
+        auto it = std::partition(items.begin() + lo, items.begin() + hi, [&](const Item& p) {
+            int b = (int)((p.c[bestAxis] - cmin) * scale);
+            b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+            return b <= bestBin;
+        });
+        int mid = (int)(it - items.begin());
+        if (mid == lo || mid == hi) mid = lo + n / 2;
+        return mid;
+    }
+
+    // fills node `ni` for items [lo,hi), hi - lo > maxLeaf (or the root)
+    void buildNode(int ni, int lo, int hi, int depth) {
+        if (depth > out->depth) out->depth = depth;
+        struct Seg { int lo, hi; };
+        Seg segs[4];
+        int ns = 1;
+        segs[0] = {lo, hi};
+        while (ns < 4) {
+            int pick = -1;
+            float best = -1.f;
+            for (int s = 0; s < ns; s++) {
+                int n = segs[s].hi - segs[s].lo;
+                if (n <= maxLeaf) continue;
+                float blo[3], bhi[3];
+                bounds(segs[s].lo, segs[s].hi, blo, bhi);
+                float score = halfArea(blo, bhi) * (float)n;
+                if (score > best) { best = score; pick = s; }
+            }
+            if (pick < 0) break;
+            int mid = split(segs[pick].lo, segs[pick].hi);
+            Seg a = {segs[pick].lo, mid}, b = {mid, segs[pick].hi};
+            for (int s = ns; s > pick + 1; s--) segs[s] = segs[s - 1];
+            segs[pick] = a;
+            segs[pick + 1] = b;
+            ns++;
+        }
+        int32_t child[4] = {kEmpty, kEmpty, kEmpty, kEmpty};
+        int childNode[4] = {-1, -1, -1, -1};
+        for (int s = 0; s < ns; s++) {
+            int n = segs[s].hi - segs[s].lo;
+            if (n <= maxLeaf) child[s] = ~(int32_t)(((uint32_t)segs[s].lo << 3) | (uint32_t)n);
+            else {
+                childNode[s] = (int)out->nodes.size();
+                child[s] = childNode[s];
+                out->nodes.emplace_back();
+            }
+        }
+        {
+            WideTree::Node& nd = out->nodes[ni];
+            for (int s = 0; s < 4; s++) {
+                nd.child[s] = child[s];
+                if (s < ns) bounds(segs[s].lo, segs[s].hi, nd.lo[s], nd.hi[s]);
+                else for (int k = 0; k < 3; k++) { nd.lo[s][k] = __builtin_inff(); nd.hi[s][k] = __builtin_inff(); }
+            }
+        }
+        for (int s = 0; s < ns; s++)
+            if (childNode[s] >= 0) buildNode(childNode[s], segs[s].lo, segs[s].hi, depth + 1);
+    }
+};
+
+}  // namespace widebvh
+
+// Build a 4-wide tree over `n` boxes with at most `maxLeaf` (1..7) items per leaf.
+inline void buildWideTree(const BuildBox* boxes, int n, int maxLeaf, WideTree& out) {
+    out.nodes.clear();
+    out.order.clear();
+    out.depth = 0;
+    widebvh::Builder b;
+    b.boxes = boxes;
+    b.out = &out;
+    b.maxLeaf = maxLeaf;
+    b.items.resize(n);
+    for (int i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) b.items[i].c[k] = (boxes[i].lo[k] + boxes[i].hi[k]) * 0.5f;
+        b.items[i].index = i;
+    }
+    out.nodes.emplace_back();
+    if (n > 0) b.buildNode(0, 0, n, 1);
+    else {
+        WideTree::Node& nd = out.nodes[0];
+        for (int s = 0; s < 4; s++) {
+            nd.child[s] = widebvh::kEmpty;
+            for (int k = 0; k < 3; k++) { nd.lo[s][k] = __builtin_inff(); nd.hi[s][k] = __builtin_inff(); }
+        }
+    }
+    out.order.resize(n);
+    for (int i = 0; i < n; i++) out.order[i] = b.items[i].index;
+}
+
+}  // namespace rt
