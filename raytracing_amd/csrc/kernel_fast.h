@@ -665,7 +665,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
 }
 
 struct FastLaunchConfig {
-    int blocksPerCU = 4, refillBelow = 40, nodeMin = 16;
+    int blocksPerCU = 4, refillBelow = 40, nodeMin = 12;
     bool stats = false;
 };
 
