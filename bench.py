@@ -70,7 +70,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from raytracing_amd import backend, types as T
+    from raytracing_amd import backend, distributed as D, types as T
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -79,15 +79,24 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RTAMD_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend, to rehearse the N>1 code
+    # path on a one-GPU box (numbers from such a run mean nothing).
+    rehearse = os.environ.get("RTAMD_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     (buf, frame, sky), desc = build_workload(args.workload, args.width, args.height, args.tree)
     W, Hh = args.width, args.height
-    rt = backend.RayTracingPass(local_rank)
+    rt = backend.RayTracingPass(dev_index)
+    # kernels, the RCCL all-reduce and the normalisation all run on torch's current stream
+    rt.SetStream(torch.cuda.current_stream().cuda_stream)
     rt.SetScene(buf)
     rt.SetSkyBox(sky)
     out = torch.zeros((Hh, W, 4), dtype=torch.float32, device=dev)
@@ -99,8 +108,7 @@ def main():
         r = rt.Execute(frame, W, Hh, out_rgba=out, mode=T.MODE_PT, spp=args.spp, max_bounces=args.bounces,
                        seed=args.seed, sample_offset=rank * args.spp, flags=flags)
         if world > 1:
-            dist.all_reduce(out, op=dist.ReduceOp.SUM)     # RCCL framebuffer reduce over xGMI
-            out.div_(out[..., 3:4].clone())
+            D.combine_samples(out)     # RCCL all-reduce (SUM) of the sum buffer over xGMI, then / sample count
         return r
 
     for _ in range(args.warmup):
