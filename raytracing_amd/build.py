@@ -53,7 +53,7 @@ def build_host(force=False):
     out = os.path.join(LIB, "librtamd_host.so")
     if force or _newer(out, deps):
         os.makedirs(LIB, exist_ok=True)
-        _run([os.environ.get("CXX", "g++")] + CXX_FLAGS + ["-I" + INC, "-I" + hdir] + srcs + ["-o", out])
+        _run([os.environ.get("CXX", "g++")] + CXX_FLAGS + ["-I" + INC, "-I" + hdir] + srcs + ["-o", out, "-lz"])
     return out
 
 

@@ -314,3 +314,28 @@ def camera(position, rotation_xyzw, fov_y_deg, aspect, z_near=0.3, z_far=1000.0)
     out = np.zeros(1, dtype=T.FRAME)
     lib().rtamd_host_camera(_ptr(_f32(position, 3)), _ptr(_f32(rotation_xyzw, 4)), fov_y_deg, aspect, z_near, z_far, _ptr(out))
     return out
+
+
+def load_image(path, flip_y=True):
+    """HDR image (.exr / .hdr) as float32 (h, w, 4).  flip_y=True gives Unity texture order
+    (row 0 = bottom of the picture), the order RayTracingPass.SetSkyBox expects."""
+    L = lib()
+    L.rtamd_host_image_load.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.rtamd_host_image_free.argtypes = [C.POINTER(C.c_float)]
+    p = C.POINTER(C.c_float)()
+    w, h = C.c_int32(), C.c_int32()
+    _check(L.rtamd_host_image_load(os.fsencode(path), 1 if flip_y else 0, C.byref(p), C.byref(w), C.byref(h)), "image_load")
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 4)).copy()
+    finally:
+        L.rtamd_host_image_free(p)
+
+
+def save_image(path, rgba, flip_y=True):
+    """Write float32 (h, w, 4) as .exr (float, ZIP), .hdr (RGBE) or .ppm (8 bits, clamped)."""
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("expected an (h, w, 4) array")
+    L = lib()
+    L.rtamd_host_image_save.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    _check(L.rtamd_host_image_save(os.fsencode(path), _ptr(a), a.shape[1], a.shape[0], 1 if flip_y else 0), "image_save")

@@ -16,10 +16,12 @@ d = sys.argv[1]
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     acc = collections.defaultdict(float)
     for row in csv.DictReader(open(f)):
-        if "kFast" in row["Kernel_Name"]:
-            acc[row["Counter_Name"]] += float(row["Counter_Value"])
+        name = row["Kernel_Name"]
+        if "rt::k" not in name: continue
+        short = name.split("rt::")[1].split("(")[0]
+        acc[(short, row["Counter_Name"])] += float(row["Counter_Value"])
     for k, v in sorted(acc.items()):
-        print(f"{k} {v:.6g}")
+        print(f"{k[0]} {k[1]} {v:.6g}")
 PY
 }
 BENCH_ARGS="$@"
