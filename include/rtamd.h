@@ -210,6 +210,19 @@ int rtamd_last_render_stats(const rtamd_ctx* ctx, float* kernel_ms, uint64_t* ra
 int rtamd_composite_add(rtamd_ctx* ctx, const float* src_rgba, uint8_t* dst_rgba8,
                         int32_t width, int32_t height);
 
+/* Tone-mapped presentation of an HDR framebuffer (a path-traced mean, which unlike
+ * the reference's single mirror bounce routinely exceeds 1): the reference has no
+ * tone map — its UNORM8 target clamps at 1 (RayTracingPass.cs:58), which is
+ * RTAMD_TONEMAP_CLAMP here.  Per channel: x = src * exposure; CLAMP: x;
+ * REINHARD: x / (1 + x); then saturate, then x^(1/gamma) when gamma is neither 0
+ * nor 1, then round(x * 255).  Alpha is saturate(src.a) * 255.  dst is overwritten
+ * (use rtamd_composite_add for the reference's additive blend).  Both buffers host
+ * or both device. */
+#define RTAMD_TONEMAP_CLAMP 0
+#define RTAMD_TONEMAP_REINHARD 1
+int rtamd_present(rtamd_ctx* ctx, const float* src_rgba, uint8_t* dst_rgba8, int32_t width,
+                  int32_t height, int32_t tonemap, float exposure, float gamma);
+
 /* Library / build identification, e.g. "rtamd 0.1 gfx950". */
 const char* rtamd_version(void);
 

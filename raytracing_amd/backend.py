@@ -16,7 +16,7 @@ _lib = None
 
 EXPORTS = ["rtamd_ctx_create", "rtamd_ctx_destroy", "rtamd_last_error_string", "rtamd_scene_upload",
            "rtamd_scene_refresh_objects", "rtamd_sky_upload", "rtamd_render", "rtamd_accum_reset",
-           "rtamd_set_stream", "rtamd_last_render_stats", "rtamd_composite_add", "rtamd_version"]
+           "rtamd_set_stream", "rtamd_last_render_stats", "rtamd_composite_add", "rtamd_present", "rtamd_version"]
 
 
 class BackendError(RuntimeError):
@@ -174,3 +174,10 @@ class RayTracingPass:
     def CompositeAdd(self, src_rgba, dst_rgba8):
         h, w = src_rgba.shape[0], src_rgba.shape[1]
         self._check(lib().rtamd_composite_add(self._ctx, _ptr(src_rgba), _ptr(dst_rgba8), w, h))
+
+    def Present(self, src_rgba, dst_rgba8, tonemap=0, exposure=1.0, gamma=1.0):
+        """Tone-mapped 8-bit copy of an HDR framebuffer (tonemap 0 = the reference's clamp, 1 = Reinhard)."""
+        h, w = src_rgba.shape[0], src_rgba.shape[1]
+        L = lib()
+        L.rtamd_present.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float]
+        self._check(L.rtamd_present(self._ctx, _ptr(src_rgba), _ptr(dst_rgba8), w, h, tonemap, exposure, gamma))

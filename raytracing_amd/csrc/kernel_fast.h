@@ -65,6 +65,8 @@ struct FastScene {
     const int32_t* superTiles;   // ids of the 32x32 pixel tiles this launch owns
     int32_t nSuperTiles;
     int32_t tlasRoot;            // index of the TLAS root in nodes
+    // nodes kept in LDS by every workgroup: [0, hotTlas) and [blasBase, blasBase + hotBlas)
+    int32_t hotTlas, blasBase, hotBlas;
 };
 
 template <typename T>
@@ -98,8 +100,11 @@ struct FastSceneHost {
     DBuf<int32_t> superTiles;
     DBuf<unsigned long long> stats;
     std::vector<int32_t> blasRoot;     // wide-node index of each BLAS root
-    std::vector<WNode> hNodes;         // BLAS nodes, then the TLAS nodes of the last upload
+    // node array: [0, tlasReserve) the TLAS of the last upload (breadth first), then every BLAS node,
+    // the top levels of all BLAS trees first (breadth first, round robin over the trees)
+    std::vector<WNode> hNodes;
     size_t nBlasNodes = 0;
+    int tlasReserve = 0, nTlasNodes = 0;
     std::vector<FInst> hInst;
     std::vector<FShade> hShade;
     std::vector<int32_t> hSuper;
@@ -112,11 +117,12 @@ struct FastSceneHost {
         superTiles.release(); stats.release();
     }
 
-    // Append the nodes of a built tree to hNodes.  leafCode(start, count) encodes a leaf.
+    // Convert the nodes of a built tree; node i of the tree gets index remap[i].
+    // leafCode(start, count) encodes a leaf.
     template <typename LeafCode>
-    int appendTree(const WideTree& t, LeafCode leafCode) {
-        const int base = (int)hNodes.size();
-        for (const WideTree::Node& n : t.nodes) {
+    void placeTree(const WideTree& t, const std::vector<int32_t>& remap, LeafCode leafCode) {
+        for (size_t i = 0; i < t.nodes.size(); i++) {
+            const WideTree::Node& n = t.nodes[i];
             WNode w;
             std::memset(&w, 0, sizeof(w));
             int32_t ch[4];
@@ -125,16 +131,32 @@ struct FastSceneHost {
                 (&w.ly.x)[s] = n.lo[s][1]; (&w.hy.x)[s] = n.hi[s][1];
                 (&w.lz.x)[s] = n.lo[s][2]; (&w.hz.x)[s] = n.hi[s][2];
                 if (n.child[s] == widebvh::kEmpty) ch[s] = kEmptyChild;     // box is all +inf: never entered
-                else if (n.child[s] >= 0) ch[s] = base + n.child[s];
+                else if (n.child[s] >= 0) ch[s] = remap[n.child[s]];
                 else {
                     uint32_t code = (uint32_t)~n.child[s];
                     ch[s] = leafCode((int)(code >> 3), (int)(code & 7u));
                 }
             }
             w.child = make_int4(ch[0], ch[1], ch[2], ch[3]);
-            hNodes.push_back(w);
+            hNodes[remap[i]] = w;
         }
-        return base;
+    }
+
+    // breadth-first order of a tree's nodes, and where each level starts in it
+    static void levelOrder(const WideTree& t, std::vector<int32_t>& order, std::vector<int32_t>& levelStart) {
+        order.clear(); levelStart.clear();
+        order.push_back(0);
+        size_t at = 0;
+        while (at < order.size()) {
+            levelStart.push_back((int32_t)at);
+            const size_t end = order.size();
+            for (; at < end; at++)
+                for (int s = 0; s < 4; s++) {
+                    int32_t c = t.nodes[order[at]].child[s];
+                    if (c >= 0) order.push_back(c);
+                }
+        }
+        levelStart.push_back((int32_t)order.size());
     }
 
     // Re-build every BLAS.  Inputs were validated by the caller (indices in range, every
@@ -143,10 +165,13 @@ struct FastSceneHost {
     // first, leaf slots 0..3: RayTracingShader.compute:293-345); the hierarchy itself is new.
     hipError_t buildBottom(const int32_t* blasOffsets, const rtamd_node* blas, const int32_t* nodeCount,
                            const int32_t* vtxOffsets, const rtamd_vertex* verts, const int32_t* triOffsets,
-                           const rtamd_int3* tris_, const int32_t* triCount, int nBlas, hipStream_t stream,
-                           std::string& err) {
+                           const rtamd_int3* tris_, const int32_t* triCount, int nBlas, int tlasReserve_,
+                           hipStream_t stream, std::string& err) {
         (void)triCount; (void)nodeCount;
+        tlasReserve = tlasReserve_ < 1 ? 1 : tlasReserve_;
         hNodes.clear();
+        std::vector<WideTree> trees((size_t)nBlas);
+        std::vector<uint32_t> triBases((size_t)nBlas);
         std::vector<FTri> ft;          // in leaf order of the new trees
         std::vector<FNrm> fn;          // by global rank
         std::vector<int32_t> orig;     // by global rank: the caller's triangle index
@@ -201,16 +226,43 @@ struct FastSceneHost {
                 }
             }
             if (fn.size() >= (1u << 28)) { err = "too many triangles for the leaf encoding"; return hipSuccess; }
-            WideTree tree;
+            WideTree& tree = trees[b];
             buildWideTree(boxes.data(), (int)boxes.size(), 4, tree);
             if (tree.depth > maxDepth) maxDepth = tree.depth;
-            const uint32_t triBase = (uint32_t)ft.size();
+            triBases[b] = (uint32_t)ft.size();
             for (int32_t it : tree.order) ft.push_back(ranked[it]);
-            blasRoot[b] = appendTree(tree, [&](int start, int count) -> int32_t {
-                return ~(int32_t)(((triBase + (uint32_t)start) << 2) | (uint32_t)(count - 1));
-            });
         }
-        nBlasNodes = hNodes.size();
+        // node indices: level by level over all trees (so that a prefix of the BLAS region holds the
+        // top of every tree), behind the TLAS region
+        {
+            std::vector<std::vector<int32_t>> order((size_t)nBlas), levelStart((size_t)nBlas), remap((size_t)nBlas);
+            size_t total = 0;
+            for (int b = 0; b < nBlas; b++) {
+                levelOrder(trees[b], order[b], levelStart[b]);
+                remap[b].assign(trees[b].nodes.size(), -1);
+                total += trees[b].nodes.size();
+            }
+            int32_t next = tlasReserve;
+            for (size_t level = 0;; level++) {
+                bool any = false;
+                for (int b = 0; b < nBlas; b++) {
+                    if (level + 1 >= levelStart[b].size()) continue;
+                    any = true;
+                    for (int32_t i = levelStart[b][level]; i < levelStart[b][level + 1]; i++) remap[b][order[b][i]] = next++;
+                }
+                if (!any) break;
+            }
+            hNodes.resize((size_t)tlasReserve + total);
+            for (int b = 0; b < nBlas; b++) {
+                const uint32_t triBase = triBases[b];
+                placeTree(trees[b], remap[b], [&](int start, int count) -> int32_t {
+                    return ~(int32_t)(((triBase + (uint32_t)start) << 2) | (uint32_t)(count - 1));
+                });
+                blasRoot[b] = remap[b][0];
+            }
+        }
+        nBlasNodes = hNodes.size() - (size_t)tlasReserve;
+        blasUploaded = false;
         hipError_t e;
         if ((e = tris.put(ft, stream)) != hipSuccess) return e;
         if ((e = nrms.put(fn, stream)) != hipSuccess) return e;
@@ -224,7 +276,6 @@ struct FastSceneHost {
     hipError_t buildTop(const rtamd_node* tlas, int nTlas, const rtamd_object_property* objects, int nObjects,
                         hipStream_t stream, std::string& err) {
         (void)nObjects; (void)nTlas;
-        hNodes.resize(nBlasNodes);
         hInst.clear(); hShade.clear();
         std::vector<BuildBox> boxes;
         std::vector<int32_t> st;
@@ -266,26 +317,40 @@ struct FastSceneHost {
         nInst = (int)hInst.size();
         WideTree tree;
         buildWideTree(boxes.data(), nInst, 1, tree);
-        tlasRoot = appendTree(tree, [&](int start, int count) -> int32_t {
-            (void)count;   // one instance per leaf: the leaf's box is the instance's own TLAS slot box
-            return ~(int32_t)((uint32_t)tree.order[start] | kInstanceBit);
-        });
+        if ((int)tree.nodes.size() > tlasReserve) { err = "TLAS grew beyond the node range reserved at scene upload"; return hipSuccess; }
+        {
+            std::vector<int32_t> order, levelStart, remap(tree.nodes.size());
+            levelOrder(tree, order, levelStart);
+            for (size_t i = 0; i < order.size(); i++) remap[order[i]] = (int32_t)i;
+            placeTree(tree, remap, [&](int start, int count) -> int32_t {
+                (void)count;   // one instance per leaf: the leaf's box is the instance's own TLAS slot box
+                return ~(int32_t)((uint32_t)tree.order[start] | kInstanceBit);
+            });
+        }
+        tlasRoot = 0;
+        nTlasNodes = (int)tree.nodes.size();
         tlasDepth = tree.depth;
         hipError_t e;
-        if ((e = nodes.put(hNodes, stream)) != hipSuccess) return e;
+        if (!blasUploaded) {
+            if ((e = nodes.put(hNodes, stream)) != hipSuccess) return e;
+            blasUploaded = true;
+        } else if ((e = hipMemcpyAsync(nodes.p, hNodes.data(), (size_t)nTlasNodes * sizeof(WNode), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
         if ((e = inst.put(hInst, stream)) != hipSuccess) return e;
         return shade.put(hShade, stream);
     }
     int tlasDepth = 0;
+    bool blasUploaded = false;
 };
 
 // ------------------------------------------------------------------ kernel ---
 
-constexpr int kBlockThreads = 256;
+constexpr int kBlockThreads = 1024;  // one workgroup per CU: its 16 waves share one LDS copy of the hot nodes
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
 #endif
-constexpr int kLdsStack = 40;        // stack entries per lane, all in LDS: [entry][thread], conflict-free
+constexpr int kLdsStack = 24;        // stack entries per lane, all in LDS: [entry][thread], conflict-free (96 KiB)
+constexpr int kHotNodes = 448;       // nodes every workgroup keeps in LDS (63 KiB): the TLAS and the top of the BLAS trees
+constexpr int kHotStride = 9;        // float4 per node in LDS: 144 bytes, so that piece j of 16 different nodes falls on 16 different bank groups
 constexpr int kModeRef = 0, kModePt = 1, kModePrimary = 2;
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -397,9 +462,20 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
         }                                                                           \
     } while (0)
     __shared__ int32_t ldsStack[kLdsStack][kBlockThreads];
+    __shared__ float4 ldsNodes[kHotNodes * kHotStride];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const unsigned long long totalWork = (unsigned long long)sc.nSuperTiles * 1024ull;
+    // An inner-node test costs seven 16-byte loads per lane, each lane in its own 128-byte line, a
+    // gather the vector cache serves one lane per cycle.  The nodes every ray passes through — the
+    // TLAS and the first levels of the BLAS trees — are therefore read from an LDS copy.
+    const int hotTlas = sc.hotTlas, hotBlas = sc.hotBlas;
+    for (int i = tid; i < (hotTlas + hotBlas) * 8; i += kBlockThreads) {
+        const int n = i >> 3, c = i & 7;
+        const int g = n < hotTlas ? n : sc.blasBase + (n - hotTlas);
+        if (c < 7) ldsNodes[n * kHotStride + c] = reinterpret_cast<const float4*>(sc.nodes + g)[c];
+    }
+    __syncthreads();
 
     // pixel state
     bool pixelActive = false, noMoreWork = false;
@@ -573,9 +649,20 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                 RT_STAT(1, atNode);
                 RT_STAT(7, trav);
                 if (atNode) {
-                    const float4* np = reinterpret_cast<const float4*>(sc.nodes + node);
-                    const float4 lx = np[0], hx = np[1], ly = np[2], hy = np[3], lz = np[4], hz = np[5];
-                    const int4 ch = reinterpret_cast<const int4*>(np)[6];
+                    int hot = -1;
+                    if (node < hotTlas) hot = node;
+                    else if ((uint32_t)(node - sc.blasBase) < (uint32_t)hotBlas) hot = hotTlas + (node - sc.blasBase);
+                    // (written as if / else the two cases compile to one generic-address load per piece; as two
+                    // separate conditionals with ds_read / global_load they need more registers and run slower)
+                    float4 lx, hx, ly, hy, lz, hz, chf;
+                    if (hot >= 0) {
+                        const float4* lp = ldsNodes + hot * kHotStride;
+                        lx = lp[0]; hx = lp[1]; ly = lp[2]; hy = lp[3]; lz = lp[4]; hz = lp[5]; chf = lp[6];
+                    } else {
+                        const float4* np = reinterpret_cast<const float4*>(sc.nodes + node);
+                        lx = np[0]; hx = np[1]; ly = np[2]; hy = np[3]; lz = np[4]; hz = np[5]; chf = np[6];
+                    }
+                    const int4 ch = make_int4(__float_as_int(chf.x), __float_as_int(chf.y), __float_as_int(chf.z), __float_as_int(chf.w));
                     const f2 ox = {cur.origin.x, cur.origin.x}, oy = {cur.origin.y, cur.origin.y}, oz = {cur.origin.z, cur.origin.z};
                     const f2 ix = {cur.invDir.x, cur.invDir.x}, iy = {cur.invDir.y, cur.invDir.y}, iz = {cur.invDir.z, cur.invDir.z};
                     float d0, d1, d2, d3;
@@ -665,13 +752,13 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
 }
 
 struct FastLaunchConfig {
-    int blocksPerCU = 4, refillBelow = 40, nodeMin = 12;
+    int blocksPerCU = 1, refillBelow = 40, nodeMin = 12;
     bool stats = false;
 };
 
 inline FastLaunchConfig fastLaunchConfig() {
     FastLaunchConfig c;
-    if (const char* s = getenv("RTAMD_BLOCKS_PER_CU")) { int v = atoi(s); if (v > 0 && v <= 8) c.blocksPerCU = v; }
+    if (const char* s = getenv("RTAMD_BLOCKS_PER_CU")) { int v = atoi(s); if (v > 0 && v <= 2) c.blocksPerCU = v; }
     if (const char* s = getenv("RTAMD_REFILL_BELOW")) { int v = atoi(s); if (v >= 1 && v <= 64) c.refillBelow = v; }
     if (const char* s = getenv("RTAMD_NODE_MIN")) { int v = atoi(s); if (v >= 1 && v <= 64) c.nodeMin = v; }
     if (const char* s = getenv("RTAMD_STATS")) c.stats = atoi(s) != 0;
@@ -702,7 +789,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
     }
     const FastLaunchConfig cfg = fastLaunchConfig();
     long long wavesNeeded = ((long long)fs.hSuper.size() * 1024 + 63) / 64;
-    long long blocksNeeded = (wavesNeeded + 3) / 4;
+    long long blocksNeeded = (wavesNeeded + kBlockThreads / 64 - 1) / (kBlockThreads / 64);
     int grid = numCU * cfg.blocksPerCU;
     if (blocksNeeded < grid) grid = (int)blocksNeeded;
     if (grid < 1) grid = 1;
@@ -711,6 +798,15 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
     sc.nodes = fs.nodes.p; sc.inst = fs.inst.p; sc.shade = fs.shade.p;
     sc.tris = fs.tris.p; sc.nrms = fs.nrms.p; sc.triOrig = fs.triOrig.p; sc.superTiles = fs.superTiles.p; sc.nSuperTiles = (int)fs.hSuper.size();
     sc.tlasRoot = fs.tlasRoot;
+    // LDS budget: the whole TLAS if it leaves half of the room (or more, when the BLAS trees are small) to the BLAS tops
+    {
+        const int nb = fs.nBlasNodes < (size_t)kHotNodes ? (int)fs.nBlasNodes : kHotNodes;
+        int tl = kHotNodes - nb > kHotNodes / 2 ? kHotNodes - nb : kHotNodes / 2;
+        if (tl > fs.nTlasNodes) tl = fs.nTlasNodes;
+        sc.hotTlas = tl;
+        sc.blasBase = fs.tlasReserve;
+        sc.hotBlas = kHotNodes - tl < nb ? kHotNodes - tl : nb;
+    }
 
     if (a.mode == RTAMD_MODE_PT && (a.outIds || a.outT)) {
         // identity of the un-jittered primary hit: a separate, uncounted pass

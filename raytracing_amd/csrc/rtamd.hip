@@ -268,7 +268,7 @@ int rtamd_scene_upload(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas, cons
 
     std::string err;
     hipError_t e = c->fast.buildBottom(blasOffsets, blas, nodeCnt.data(), vtxOffsets, verts, triOffsets, tris,
-                                       triCnt.data(), nBlas, c->stream, err);
+                                       triCnt.data(), nBlas, nObjects, c->stream, err);
     if (e != hipSuccess) return failHip(c, e, "BLAS re-pack");
     if (!err.empty()) return fail(c, RTAMD_ERR_BAD_INDEX, err);
 
@@ -506,6 +506,51 @@ extern "C" int rtamd_composite_add(rtamd_ctx* c, const float* src, uint8_t* dst,
         ds = c->outRgba.p; dd = tmp.p;
     }
     hipLaunchKernelGGL(rt::kCompositeAdd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ds, dd, n);
+    HIP_TRY(c, hipGetLastError());
+    if (!sDev) HIP_TRY(c, hipMemcpyAsync(dst, dd, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    tmp.release();
+    return RTAMD_OK;
+}
+
+namespace rt {
+__global__ void kPresent(const float4* src, uchar4* dst, size_t n, int tonemap, float exposure, float invGamma) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 s = src[i];
+    float c[3] = {s.x * exposure, s.y * exposure, s.z * exposure};
+    unsigned char q[3];
+    for (int k = 0; k < 3; k++) {
+        float x = c[k];
+        if (tonemap == RTAMD_TONEMAP_REINHARD) x = x / (1.0f + x);
+        x = saturate(x);
+        if (invGamma != 1.0f) x = __builtin_powf(x, invGamma);
+        q[k] = (unsigned char)__builtin_floorf(x * 255.0f + 0.5f);
+    }
+    dst[i] = make_uchar4(q[0], q[1], q[2], (unsigned char)__builtin_floorf(saturate(s.w) * 255.0f + 0.5f));
+}
+}  // namespace rt
+
+extern "C" int rtamd_present(rtamd_ctx* c, const float* src, uint8_t* dst, int32_t width, int32_t height, int32_t tonemap,
+                             float exposure, float gamma) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!src || !dst || width <= 0 || height <= 0) return fail(c, RTAMD_ERR_INVALID_ARG, "NULL buffer or bad size");
+    if (tonemap != RTAMD_TONEMAP_CLAMP && tonemap != RTAMD_TONEMAP_REINHARD) return fail(c, RTAMD_ERR_INVALID_ARG, "unknown tone map");
+    if (!(exposure >= 0.0f) || !(gamma >= 0.0f)) return fail(c, RTAMD_ERR_INVALID_ARG, "exposure and gamma must be >= 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t n = (size_t)width * height;
+    bool sDev = isDevicePointer(src), dDev = isDevicePointer(dst);
+    if (sDev != dDev) return fail(c, RTAMD_ERR_INVALID_ARG, "src and dst must both be host or both be device memory");
+    const float4* ds = (const float4*)src;
+    uchar4* dd = (uchar4*)dst;
+    DevBuf<uchar4> tmp;
+    if (!sDev) {
+        HIP_TRY(c, c->outRgba.upload((const float4*)src, n, c->stream));
+        HIP_TRY(c, tmp.alloc(n));
+        ds = c->outRgba.p; dd = tmp.p;
+    }
+    const float invGamma = (gamma == 0.0f || gamma == 1.0f) ? 1.0f : 1.0f / gamma;
+    hipLaunchKernelGGL(rt::kPresent, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, ds, dd, n, tonemap, exposure, invGamma);
     HIP_TRY(c, hipGetLastError());
     if (!sDev) HIP_TRY(c, hipMemcpyAsync(dst, dd, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -165,6 +165,30 @@ def test_composite_add_is_the_reference_blit(gpu_pass):
     assert np.array_equal(out[src[..., 3] == 0], dst[src[..., 3] == 0])   # alpha 0: the raster image shows through
 
 
+def test_present_tone_maps(gpu_pass):
+    rs = np.random.RandomState(1)
+    src = rs.uniform(0, 6.0, size=(7, 20, 4)).astype(np.float32)
+    src[..., 3] = rs.uniform(0, 1.2, size=(7, 20))
+    one, h, q = np.float32(1), np.float32(0.5), np.float32(255)
+
+    def quant(x):
+        return np.floor(np.clip(x, 0, 1) * q + h).astype(np.uint8)
+
+    out = np.zeros((7, 20, 4), dtype=np.uint8)
+    gpu_pass.Present(src, out)                                   # the reference's behaviour: clamp at 1
+    assert np.array_equal(out, quant(src))
+    gpu_pass.Present(src, out, tonemap=1, exposure=0.5)          # Reinhard, correctly rounded divide: exact
+    x = src[..., :3] * h
+    assert np.array_equal(out[..., :3], quant(x / (one + x)))
+    assert np.array_equal(out[..., 3], quant(src[..., 3]))
+    gpu_pass.Present(src, out, tonemap=1, gamma=2.2)             # powf: within one 8-bit step
+    x = src[..., :3]
+    want = quant(np.power(np.clip(x / (one + x), 0, 1), one / np.float32(2.2)))
+    assert np.abs(out[..., :3].astype(np.int32) - want.astype(np.int32)).max() <= 1
+    with pytest.raises(backend.BackendError):
+        gpu_pass.Present(src, out, tonemap=7)
+
+
 def test_error_codes(scene_few):
     buf, frame, _ = scene_few
     p = backend.RayTracingPass(0)
