@@ -13,7 +13,9 @@
 //     (build with -ffp-contract=off), subnormals kept;
 //   * dot(a,b)   = (a.x*b.x + a.y*b.y) + a.z*b.z
 //   * mul(M,v)   = per row ((m0*v.x + m1*v.y) + m2*v.z) [+ m3 when w == 1]
-//   * normalize  = v / sqrt(dot(v,v))     (true division, true sqrt)
+//   * normalize  = v * (1 / sqrt(dot(v,v)))  (one true division, true sqrt; HLSL's own form is v * rsqrt)
+//   * a division by a constant or by a per-frame value (pi, image size, sky size, the roulette sum) is a
+//     multiplication by its correctly rounded reciprocal, as an HLSL compiler emits it
 //   * reflect    = i - (2*dot(n,i))*n
 //   * min / max  = fminf / fmaxf (a NaN operand is ignored)
 //   * 1.#INF     = +infinity
@@ -104,8 +106,8 @@ static inline float3 cross(float3 a, float3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 static inline float3 normalize(float3 v) {
-    float l = std::sqrt(dot(v, v));
-    return {v.x / l, v.y / l, v.z / l};
+    float r = 1.0f / std::sqrt(dot(v, v));
+    return {v.x * r, v.y * r, v.z * r};
 }
 // fminf / fmaxf semantics (the non-NaN operand wins) without the libm call.
 static inline float ofmin(float a, float b) { float r = a < b ? a : b; return b != b ? a : r; }
@@ -126,6 +128,7 @@ static inline float3 mulDir(const float* m, float3 v) {
 }
 
 static const float PI = 3.14159265f;       // .compute:24
+static const float NEG_INV_PI = -0.318309886f;   // 1 / -PI
 static const float EPSILON = 1e-8f;        // .compute:27
 static const float INF = std::numeric_limits<float>::infinity();
 
@@ -407,8 +410,8 @@ static inline float3 sampleSky(const Scene& sc, float u, float v) {
     float fx = x - x0f, fy = y - y0f;
     // wrap in float first so that huge |u| cannot overflow the int conversion
     float W = (float)sc.skyW, H = (float)sc.skyH;
-    float xw = x0f - std::floor(x0f / W) * W;
-    float yw = y0f - std::floor(y0f / H) * H;
+    float xw = x0f - std::floor(x0f * (1.0f / W)) * W;
+    float yw = y0f - std::floor(y0f * (1.0f / H)) * H;
     int x0 = (int)xw, y0 = (int)yw;
     if (x0 < 0) x0 = 0; if (x0 >= sc.skyW) x0 = sc.skyW - 1;
     if (y0 < 0) y0 = 0; if (y0 >= sc.skyH) y0 = sc.skyH - 1;
@@ -428,8 +431,8 @@ static inline float3 sampleSky(const Scene& sc, float u, float v) {
 
 // Miss branch of Shade.  .compute:402-410
 static inline float3 shadeMiss(const Scene& sc, float3 dir) {
-    float theta = acosDecl(dir.y) / -PI;
-    float phi = atan2Decl(dir.x, -dir.z) / -PI * 0.5f;
+    float theta = acosDecl(dir.y) * NEG_INV_PI;
+    float phi = atan2Decl(dir.x, -dir.z) * NEG_INV_PI * 0.5f;
     return sampleSky(sc, phi, theta);
 }
 
@@ -496,8 +499,9 @@ static inline float3 tracePath(Tracer& tr, Ray ray, uint32_t key, int maxBounces
         float diffChance = energyOf(alb);
         float sum = specChance + diffChance;
         if (!(sum > 0.0f)) break;
-        specChance = specChance / sum;
-        diffChance = diffChance / sum;
+        float rsum = 1.0f / sum;
+        specChance = specChance * rsum;
+        diffChance = diffChance * rsum;
         float roulette = rngDraw(key, 2u + 3u * (uint32_t)b);
         float3 dir;
         if (roulette < specChance) {
@@ -538,8 +542,8 @@ static void renderRows(const Scene& sc, const FrameCBuffer& cb, const Params& p,
             size_t pix = (size_t)y * width + x;
             // CSMain: uv = (id.xy + _PixelOffset) / (w,h) * 2 - 1.  .compute:439
             if (p.mode == 0 || ids || tout) {
-                float u = ((float)x + cb.PixelOffset[0]) / (float)width * 2.0f - 1.0f;
-                float v = ((float)y + cb.PixelOffset[1]) / (float)height * 2.0f - 1.0f;
+                float u = ((float)x + cb.PixelOffset[0]) * (1.0f / (float)width) * 2.0f - 1.0f;
+                float v = ((float)y + cb.PixelOffset[1]) * (1.0f / (float)height) * 2.0f - 1.0f;
                 Ray cam = CreateCameraRay(cb, u, v);
                 float px[4];
                 RayHit h;
@@ -559,8 +563,8 @@ static void renderRows(const Scene& sc, const FrameCBuffer& cb, const Params& p,
                     uint32_t key = rngKey(p.seed, (uint32_t)pix, (uint32_t)(p.sample_offset + s));
                     float jx = cb.PixelOffset[0], jy = cb.PixelOffset[1];
                     if (!(p.flags & 2u)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
-                    float u = ((float)x + jx) / (float)width * 2.0f - 1.0f;
-                    float v = ((float)y + jy) / (float)height * 2.0f - 1.0f;
+                    float u = ((float)x + jx) * (1.0f / (float)width) * 2.0f - 1.0f;
+                    float v = ((float)y + jy) * (1.0f / (float)height) * 2.0f - 1.0f;
                     Ray cam = CreateCameraRay(cb, u, v);
                     sum = sum + tracePath(tr, cam, key, p.max_bounces);
                 }
@@ -637,8 +641,8 @@ int oracle_bruteforce_primary(const Scene* sc, const FrameCBuffer* cb, int width
     for (int y = 0; y < height; y++)
         for (int x = 0; x < width; x++) {
             size_t pix = (size_t)y * width + x;
-            float u = ((float)x + cb->PixelOffset[0]) / (float)width * 2.0f - 1.0f;
-            float v = ((float)y + cb->PixelOffset[1]) / (float)height * 2.0f - 1.0f;
+            float u = ((float)x + cb->PixelOffset[0]) * (1.0f / (float)width) * 2.0f - 1.0f;
+            float v = ((float)y + cb->PixelOffset[1]) * (1.0f / (float)height) * 2.0f - 1.0f;
             Ray ray = CreateCameraRay(*cb, u, v);
             float best = INF; int bo = -1, bt = -1, nt = 0;
             for (int o = 0; o < sc->nObjects; o++) {

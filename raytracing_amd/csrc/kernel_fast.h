@@ -531,7 +531,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
         RT_STAT(0, !trav);
         if (!trav) {
             bool haveRay = false;
-            Ray next = world;
+            V3 nextO = world.origin, nextD = world.direction;    // the reciprocal direction is formed once, below
             if (pathActive) {
                 // the segment just traversed
                 if (best.t < RT_INF) {
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                         L = L + energy * s.emission;
                         V3 dir;
                         if (bounce < a.maxBounces && scatter(s.albedo, s.specular, s.normal, world.direction, key, (uint32_t)bounce, energy, dir)) {
-                            next = makeRay(s.position + s.normal * 0.001f, dir);
+                            nextO = s.position + s.normal * 0.001f; nextD = dir;
                             bounce++;
                             haveRay = true;
                         }
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                             if (a.outT) a.outT[pix] = best.t;
                             if (MODE == kModeRef) {
                                 // Trace: mirror ray from the hit position, no offset (.compute:419)
-                                next = makeRay(s.position, reflect(world.direction, s.normal));
+                                nextO = s.position; nextD = reflect(world.direction, s.normal);
                                 bounce = 1;
                                 haveRay = true;
                             }
@@ -622,12 +622,14 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                     key = rngKey(a.seedHi, a.seedLo, (uint32_t)((size_t)py * a.width + px), (uint32_t)(a.sampleOffset + sample));
                     if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
                 }
-                next = cameraRay(a.cb, pixelToNdc(px, jx, a.width), pixelToNdc(py, jy, a.height));
+                const Ray cam = cameraRay(a.cb, pixelToNdc(px, jx, a.invWidth), pixelToNdc(py, jy, a.invHeight));
+                nextO = cam.origin; nextD = cam.direction;
                 energy = v3(1, 1, 1); L = v3(0, 0, 0); bounce = 0;
                 pathActive = true;
                 haveRay = true;
             }
             if (haveRay) {
+                const Ray next = makeRay(nextO, nextD);
                 world = next; cur = next;
                 best.t = RT_INF; best.inst = -1; best.tri = -1;
                 node = sc.tlasRoot; sp = 0; instSp = -1; curInst = -1;

@@ -337,6 +337,7 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
     std::memset(&a, 0, sizeof(a));
     a.cb = *frame;
     a.width = width; a.height = height;
+    a.invWidth = 1.0f / (float)width; a.invHeight = 1.0f / (float)height;
     a.mode = e.mode; a.spp = e.mode == RTAMD_MODE_PT ? e.spp : 1; a.maxBounces = e.max_bounces;
     a.seedHi = (uint32_t)(e.seed >> 32); a.seedLo = (uint32_t)e.seed;
     a.sampleOffset = e.sample_offset;
@@ -385,6 +386,7 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
 
     rt::Sky sky;
     sky.texels = c->sky.p; sky.w = c->skyW; sky.h = c->skyH;
+    sky.invW = c->skyW > 0 ? 1.0f / (float)c->skyW : 0.f; sky.invH = c->skyH > 0 ? 1.0f / (float)c->skyH : 0.f;
 
     rt::DevCounters hc;
     unsigned long long hr[2] = {0, 0};
