@@ -80,6 +80,12 @@ int rtamd_host_set_entity_transform(rtamd_host_scene* s, int32_t entity, const f
  * (WorldToLocal = inverse(LocalToWorld)). */
 int rtamd_host_scene_update(rtamd_host_scene* s);
 
+/* Builder of the TLAS in rtamd_host_scene_update: 0 (default) the reference's three-job
+ * median build (BoundingVolumeHierarchyBuilder.cs:482-527), which its own fixed-size
+ * arrays limit to roughly 1 300 objects (the update then fails with a message instead
+ * of overrunning them as the reference would); 1 the binned-SAH builder, any count. */
+int rtamd_host_scene_set_tlas_builder(rtamd_host_scene* s, int32_t tree);
+
 typedef struct rtamd_host_buffers {
     const rtamd_node* tlas; int32_t n_tlas_nodes;
     const int32_t* blas_offsets;

@@ -304,7 +304,11 @@ int bvhBuild(rtamd_point_and_index* points, const rtamd_aabb* aabbs, int n, rtam
 int bvhBuildJobs(rtamd_point_and_index* points, const rtamd_aabb* aabbs, int n, rtamd_node* nodes, int capacity,
                  int* branchCountOut) {
     if (capacity < 2 || n <= 0) return RTAMD_ERR_INVALID_ARG;
-    Range levelA[kMaxNumTreeBranches + 4], levelB[kMaxNumTreeBranches + 4];
+    // The reference keeps each level in a 64-entry stack array (:647-648) and appends ranges it does not
+    // split without a bound check (:690), so a level can outgrow the array.  The arrays here are large
+    // enough to notice that (a level of 60 can grow by 4 plus at most the 60 ranges of the level before)
+    // and the build is then refused instead of overrunning them.
+    Range levelA[2 * kMaxNumTreeBranches + 8], levelB[2 * kMaxNumTreeBranches + 8];
     Range* level0 = levelA;
     Range* level1 = levelB;
     int level0Size = 1, level1Size = 0;
@@ -339,6 +343,10 @@ int bvhBuildJobs(rtamd_point_and_index* points, const rtamd_aabb* aabbs, int n, 
                 largestRangeInLastLevel = std::max(largestRangeInLastLevel, level0[i].Length);
                 minTreeNodeLevel = std::min(minTreeNodeLevel, level0[i].Depth);
             }
+        }
+        if (level1Size > kMaxNumTreeBranches) {
+            setLastError("the reference's first-levels pass overruns its 64-entry range arrays for this input (BoundingVolumeHierarchyBuilder.cs:647-690)");
+            return RTAMD_ERR_BAD_INDEX;
         }
         std::swap(level0, level1);
         level0Size = level1Size;
@@ -377,6 +385,14 @@ int bvhBuildJobs(rtamd_point_and_index* points, const rtamd_aabb* aabbs, int n, 
         b.nodes = nodes; b.capacity = capacity; b.points = points; b.freeNodeIndex = firstNodeIndex;
         b.build(range);
         if (b.failed || b.freeNodeIndex > capacity) return RTAMD_ERR_BAD_INDEX;
+        // A branch owns as many nodes as it has primitives (:502-510).  With many coincident points
+        // (every instance of a mesh carries the mesh's own centre, BuildAccelerateStructureSystem.cs:
+        // 212-214) the halving fallback can need more, and the reference's branch job then writes into
+        // its neighbour's nodes.  Reported instead of returning a corrupt tree.
+        if (b.freeNodeIndex > firstNodeIndex + range.Length) {
+            setLastError("a TLAS branch needs more nodes than the reference reserves for it (too many instances share one centre)");
+            return RTAMD_ERR_BAD_INDEX;
+        }
         refit(nodes, aabbs, firstNodeIndex, b.freeNodeIndex - 1);
         refitNode(nodes, range.Root);
         minBranchNodeIndex = i == 0 ? firstNodeIndex - 1 : std::min(firstNodeIndex - 1, minBranchNodeIndex);

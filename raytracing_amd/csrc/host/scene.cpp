@@ -59,6 +59,7 @@ struct rtamd_host_scene {
     std::vector<rtamd_object_property> objects;
     int nBlas = 0;
     int branchCount = 0;
+    int tlasTree = 0;     // 0: the reference's three-job median build, 1: binned SAH
 };
 
 extern "C" {
@@ -81,6 +82,12 @@ int rtamd_host_bvh_build_sah(const rtamd_aabb* aabbs, int32_t n, rtamd_node* nod
 }
 
 rtamd_host_scene* rtamd_host_scene_create(void) { return new (std::nothrow) rtamd_host_scene(); }
+
+int rtamd_host_scene_set_tlas_builder(rtamd_host_scene* s, int32_t tree) {
+    if (!s || (tree != 0 && tree != 1)) return RTAMD_ERR_INVALID_ARG;
+    s->tlasTree = tree;
+    return RTAMD_OK;
+}
 void rtamd_host_scene_destroy(rtamd_host_scene* s) { delete s; }
 
 // RayTraceableBaker.cs:75-149
@@ -175,11 +182,22 @@ int rtamd_host_scene_update(rtamd_host_scene* s) {
         }
         for (int k = 0; k < 3; k++) { aabbs[e].Min[k] = mnw[k]; aabbs[e].Max[k] = mxw[k]; }
     }
-    // TLAS.ScheduleBuildTree: NodeCount = BodyCount + MaxNumTreeBranches (TopLevelAccelerateStructure.cs:17)
-    int tlasCount = n + 64;
+    // TLAS.ScheduleBuildTree: NodeCount = BodyCount + MaxNumTreeBranches (TopLevelAccelerateStructure.cs:17).
+    // That is too small once the first levels take more than 64 nodes (2 + 4 + 16 + 64 = 86 with 64
+    // branches): each branch is given a node range as long as its primitive range, behind those 86,
+    // and the last branches then write past BodyCount + 64 (seen from about 1 280 bodies).  The array
+    // here has room for the 86; the tree built is the one the reference's code describes.
+    int tlasCount = n + 128;
     s->tlas.assign((size_t)tlasCount, rtamd_node{});
-    int rc = bvhBuildJobs(pts.data(), aabbs.data(), n, s->tlas.data(), tlasCount, &s->branchCount);
-    if (rc != RTAMD_OK) { setLastError("TLAS build failed"); return rc; }
+    int rc;
+    if (s->tlasTree == 1) {
+        int used = 0;
+        rc = bvhBuildSah(aabbs.data(), n, s->tlas.data(), tlasCount, &used);
+        s->branchCount = 0;
+    } else {
+        rc = bvhBuildJobs(pts.data(), aabbs.data(), n, s->tlas.data(), tlasCount, &s->branchCount);
+    }
+    if (rc != RTAMD_OK) { setLastError(std::string("TLAS build failed: ") + rtamd_host_last_error()); return rc; }
 
     // BLAS index by first use, :70-94
     std::vector<int> blasIndexOfBlob(s->blobs.size(), -1);

@@ -17,7 +17,16 @@
 //   * the one case where the caller's own inner boxes decide a hit — a ray with a zero
 //     direction component lying exactly in a box face (0 * inf = NaN is ignored by min/max,
 //     the box is missed and with it everything below) — is detected per ray segment, and the
-//     pixel is handed to the reference-order kernel.
+//     pixel is handed to the reference-order kernel;
+//   * the reference's result can depend on its visiting order when two triangles are hit at
+//     distances a rounding error apart: it tests a slot only if the slot's box is entered before
+//     the closest hit so far, and a box's computed entry distance may exceed the computed hit
+//     distance of its own triangle by an ulp or two — whether that triangle is then tested
+//     depends on what was found before it.  Here boxes are culled against the closest hit times
+//     (1 + 2^-12), so such triangles are all tested, the closest one wins, and the segment is
+//     declared ambiguous when another triangle was hit closer than the entry distance of the
+//     winner's own boxes (slot box and instance box): only then could the reference have culled
+//     the winner.  Ambiguous pixels go to the reference-order kernel as well.
 //
 // Layout (arrays 128-byte aligned in HBM; a lane's node is exactly one 128-byte line):
 //   WNode  128 B  lx,hx,ly,hy,lz,hz (float4 = the four children), child[4], pad;
@@ -25,7 +34,7 @@
 //   FTri    64 B  (lo.xyz,hi.x)(hi.yz,rank,v0.x)(v0.yz,e1.xy)(e1.z,e2.xyz) — leaf order of the new tree;
 //                 rank = position in the reference's visiting order
 //   FNrm    48 B  n0,n1,n2, indexed by rank                  — read once per closest hit
-//   FInst   64 B  three rows of WorldToLocal, BLAS root, original object index
+//   FInst   96 B  three rows of WorldToLocal, the instance's TLAS slot box, BLAS root, original object index
 //   FShade  96 B  three rows of LocalToWorld, albedo, specular, emission
 #pragma once
 
@@ -47,7 +56,7 @@ struct alignas(128) WNode {
 };
 struct alignas(64) FTri { float4 a, b, c, d; };
 struct alignas(16) FNrm { float4 a, b, c; };                            // n0.xyz n1.x | n1.yz n2.xy | n2.z
-struct alignas(64) FInst { float4 r0, r1, r2; int32_t root, object, pad0, pad1; };
+struct alignas(32) FInst { float4 r0, r1, r2; float4 b0; float bhy, bhz; int32_t root, object; float4 pad; };   // b0 = lo.xyz, hi.x
 struct alignas(32) FShade { float4 r0, r1, r2; float4 albedo, specular, emission; };
 
 // child / stack words: >= 0 node index; < 0: ~payload, payload bit 30 set = instance rank,
@@ -297,7 +306,8 @@ struct FastSceneHost {
                 fi.r0 = make_float4(m[0], m[4], m[8], m[12]);
                 fi.r1 = make_float4(m[1], m[5], m[9], m[13]);
                 fi.r2 = make_float4(m[2], m[6], m[10], m[14]);
-                fi.root = blasRoot[o.BLASIndex]; fi.object = d; fi.pad0 = fi.pad1 = 0;
+                fi.b0 = make_float4(n.Lx[i], n.Ly[i], n.Lz[i], n.Hx[i]); fi.bhy = n.Hy[i]; fi.bhz = n.Hz[i];
+                fi.root = blasRoot[o.BLASIndex]; fi.object = d; fi.pad = make_float4(0.f, 0.f, 0.f, 0.f);
                 hInst.push_back(fi);
                 FShade fs;
                 const float* l = o.LocalToWorld;
@@ -400,6 +410,17 @@ __device__ __forceinline__ bool slabHit(float lo_x, float hi_x, float lo_y, floa
     return nearMax <= farMin;
 }
 
+// Entry distance of the same test (its nearMax).
+__device__ __forceinline__ float slabNear(float lo_x, float hi_x, float lo_y, float hi_y, float lo_z, float hi_z, const Ray& r) {
+    float nearXt = (lo_x - r.origin.x) * r.invDir.x, farXt = (hi_x - r.origin.x) * r.invDir.x;
+    float nearYt = (lo_y - r.origin.y) * r.invDir.y, farYt = (hi_y - r.origin.y) * r.invDir.y;
+    float nearZt = (lo_z - r.origin.z) * r.invDir.z, farZt = (hi_z - r.origin.z) * r.invDir.z;
+    return fmax_(fmax_(fmax_(fmin_(nearXt, farXt), fmin_(nearYt, farYt)), fmin_(nearZt, farZt)), 0.0f);
+}
+
+// Boxes are culled against the closest hit so far times this factor (see the file header).
+#define RT_CULL_RELAX 1.000244140625f   /* 1 + 2^-12 */
+
 __device__ __forceinline__ void cswap(float& da, int32_t& ca, float& db, int32_t& cb) {
     bool sw = db < da;
     float td = sw ? db : da; float tb = sw ? da : db;
@@ -493,6 +514,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
     Ray cur = world;
     FastHit best;
     best.t = RT_INF; best.u = best.v = 0; best.inst = -1; best.tri = -1;
+    float secondT = RT_INF;   // closest hit among the triangles that are not `best`
+    float bestNear = 0.0f;    // entry distance of best's slot box and instance box, whichever is larger
+    float instNear = 0.0f;    // entry distance of the current instance's TLAS slot box
     int32_t node = 0;
     int sp = 0;
     int instSp = -1;          // stack height on entering the current instance, -1 outside
@@ -532,6 +556,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
         if (!trav) {
             bool haveRay = false;
             V3 nextO = world.origin, nextD = world.direction;    // the reciprocal direction is formed once, below
+            // another triangle was hit before the winner's own boxes are entered: the reference's answer
+            // depends on its visiting order
+            if (pathActive && best.t < RT_INF && secondT < bestNear) RT_REDO();
             if (pathActive) {
                 // the segment just traversed
                 if (best.t < RT_INF) {
@@ -632,6 +659,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                 const Ray next = makeRay(nextO, nextD);
                 world = next; cur = next;
                 best.t = RT_INF; best.inst = -1; best.tri = -1;
+                secondT = RT_INF; bestNear = 0.0f;
                 node = sc.tlasRoot; sp = 0; instSp = -1; curInst = -1;
                 trav = true;
                 pixRays++;
@@ -668,10 +696,11 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                     const f2 ox = {cur.origin.x, cur.origin.x}, oy = {cur.origin.y, cur.origin.y}, oz = {cur.origin.z, cur.origin.z};
                     const f2 ix = {cur.invDir.x, cur.invDir.x}, iy = {cur.invDir.y, cur.invDir.y}, iz = {cur.invDir.z, cur.invDir.z};
                     float d0, d1, d2, d3;
+                    const float cullT = best.t * RT_CULL_RELAX;
                     slabPair(f2{lx.x, lx.y}, f2{hx.x, hx.y}, f2{ly.x, ly.y}, f2{hy.x, hy.y}, f2{lz.x, lz.y}, f2{hz.x, hz.y},
-                             ox, oy, oz, ix, iy, iz, best.t, d0, d1);
+                             ox, oy, oz, ix, iy, iz, cullT, d0, d1);
                     slabPair(f2{lx.z, lx.w}, f2{hx.z, hx.w}, f2{ly.z, ly.w}, f2{hy.z, hy.w}, f2{lz.z, lz.w}, f2{hz.z, hz.w},
-                             ox, oy, oz, ix, iy, iz, best.t, d2, d3);
+                             ox, oy, oz, ix, iy, iz, cullT, d2, d3);
                     int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
                     // (empty slots carry an all-+inf box: their entry distance is +inf, a miss)
                     const int nh = (d0 < RT_INF) + (d1 < RT_INF) + (d2 < RT_INF) + (d3 < RT_INF);
@@ -696,6 +725,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                     // enter an instance (.compute:279-287)
                     const int rank = (int)(code & (kInstanceBit - 1u));
                     const FInst fi = sc.inst[rank];
+                    instNear = slabNear(fi.b0.x, fi.b0.w, fi.b0.y, fi.bhy, fi.b0.z, fi.bhz, world);
                     cur = makeRay(rowsPoint(fi.r0, fi.r1, fi.r2, world.origin), rowsDir(fi.r0, fi.r1, fi.r2, world.direction));
                     instSp = sp;
                     node = fi.root;
@@ -704,7 +734,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                 } else {
                     const uint32_t start = code >> 2;
                     const int cnt = (int)(code & 3u) + 1;
-                    const float tEntry = best.t;   // the reference masks all four slots before testing any (:298)
+                    const float tEntry = best.t * RT_CULL_RELAX;   // the reference masks all four slots before testing any (:298)
                     uint32_t mask = 0;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -726,7 +756,12 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                             const int32_t ti = __float_as_int(B.z);
                             const bool closer = t < best.t;
                             const bool tie = t == best.t && (curInst < best.inst || (curInst == best.inst && ti < best.tri));
-                            if (closer || tie) { best.t = t; best.u = u; best.v = v; best.inst = curInst; best.tri = ti; }
+                            if (closer || tie) {
+                                const float4 A = tp[0];
+                                secondT = fmin_(secondT, best.t);
+                                bestNear = fmax_(slabNear(A.x, A.w, A.y, B.x, A.z, B.y, cur), instNear);
+                                best.t = t; best.u = u; best.v = v; best.inst = curInst; best.tri = ti;
+                            } else secondT = fmin_(secondT, t);
                         }
                     }
                     RT_POP();

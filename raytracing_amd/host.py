@@ -153,9 +153,11 @@ class BoundingVolumeHierarchy:
 
     @staticmethod
     def ScheduleBuildJobs(points, aabbs):
-        """The three-job build used for the TLAS (:482-527). Returns (nodes[n+64], branchCount)."""
+        """The three-job build used for the TLAS (:482-527). Returns (nodes, branchCount).  The node
+        array is BodyCount + 128 long: the reference's BodyCount + 64 (TopLevelAccelerateStructure.cs:17)
+        overflows when the first levels alone take 86 nodes."""
         n = len(aabbs)
-        nodes = np.zeros(n + 64, dtype=T.NODE)
+        nodes = np.zeros(n + 128, dtype=T.NODE)
         bc = C.c_int32(0)
         _check(lib().rtamd_host_bvh_build_jobs(_ptr(points), _ptr(aabbs), n, _ptr(nodes), len(nodes), C.byref(bc)), "ScheduleBuildJobs")
         return nodes, bc.value
@@ -215,11 +217,14 @@ class BuildAccelerateStructureSystem:
 
     MEDIAN, SAH = 0, 1
 
-    def __init__(self):
+    def __init__(self, tlas_tree=MEDIAN):
         self._s = lib().rtamd_host_scene_create()
         if not self._s:
             raise MemoryError("rtamd_host_scene_create")
         self.ObjectsCount = 0
+        if tlas_tree != self.MEDIAN:
+            lib().rtamd_host_scene_set_tlas_builder.argtypes = [C.c_void_p, C.c_int32]
+            _check(lib().rtamd_host_scene_set_tlas_builder(self._s, tlas_tree), "set_tlas_builder")
 
     def close(self):
         if self._s:

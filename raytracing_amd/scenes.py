@@ -182,11 +182,12 @@ def reference_scene(models_dir, width=1920, height=1080):
     return buf, frame, procedural_sky()
 
 
-def instanced_scene(width=1920, height=1080, instances=1250, tris_per_blas=40_000, seed=5):
+def instanced_scene(width=1920, height=1080, instances=1250, tris_per_blas=40_000, seed=5, tlas_tree=0):
     """Config 5 shape: many instances of a few ~40 k-triangle meshes with seeded random
-    transforms (instances * tris_per_blas instanced triangles)."""
+    transforms (instances * tris_per_blas instanced triangles).  tlas_tree=1 builds the TLAS
+    with the SAH builder (the reference's own TLAS builder gives up beyond about 1 300 objects)."""
     rs = np.random.RandomState(seed)
-    sys = H.BuildAccelerateStructureSystem()
+    sys = H.BuildAccelerateStructureSystem(tlas_tree=tlas_tree)
     rings = max(4, int(round(np.sqrt(tris_per_blas / 4.0))))
     blas = [sys.BakeBLAS(_bumpy_sphere(2 * rings, rings, 100 + k)) for k in range(3)]
     quad = sys.BakeBLAS(H.Mesh.quad())

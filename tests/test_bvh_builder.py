@@ -70,10 +70,11 @@ def test_integrity_checker_detects_damage(oracle):
     assert oracle.check_integrity(bad, n) in (1, 2)
 
 
-@pytest.mark.parametrize("n", [1, 4, 5, 33, 100, 200, 485, 2000])
+@pytest.mark.parametrize("n", [1, 4, 5, 33, 100, 200, 485, 1400, 1601, 2000])
 def test_tlas_job_build(oracle, n):
     """ScheduleBuildJobs (:482-527) for object counts on both sides of every threshold,
-    including the 129..900 range where the reference's first-levels loop does not end."""
+    including the 129..900 range where the reference's first-levels loop does not end and the
+    range from about 1 280 where its BodyCount + 64 node array is too short."""
     rs = np.random.RandomState(n)
     aabbs = np.zeros(n, dtype=T.AABB)
     c = rs.uniform(-20, 20, size=(n, 3)).astype(np.float32)
@@ -83,7 +84,7 @@ def test_tlas_job_build(oracle, n):
     pts["Position"] = c
     pts["Index"] = np.arange(n)
     nodes, branches = H.BoundingVolumeHierarchy.ScheduleBuildJobs(pts, aabbs)
-    assert len(nodes) == n + 64                              # TopLevelAccelerateStructure.cs:17
+    assert len(nodes) == n + 128                             # BodyCount + 64 in TopLevelAccelerateStructure.cs:17, plus room for the 86 first-level nodes
     assert 1 <= branches <= 64
     assert oracle.check_integrity(nodes, n) == 0
 

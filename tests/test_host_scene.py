@@ -87,7 +87,7 @@ def test_on_update_flattening(oracle):
     assert unused == 2 and b.n_blas == 2                       # BLAS index by first use (:70-83)
     assert b.objects["BLASIndex"].tolist() == [0, 1, 1]
     assert b.blas_offsets.tolist() == [0, 3] and b.triangles_offsets.tolist() == [0, 2] and b.vertices_offsets.tolist() == [0, 4]
-    assert len(b.tlas) == 3 + 64                               # TopLevelAccelerateStructure.cs:17
+    assert len(b.tlas) == 3 + 128                              # BodyCount + 64 (TopLevelAccelerateStructure.cs:17) + room for the first levels
     assert np.allclose(b.objects["albedo"][1], [0.1, 0.2, 0.3, 1])
     assert np.allclose(b.objects["emission"][2], [1, 2, 3, 1])
     for o in b.objects:
@@ -141,3 +141,17 @@ def test_config_scenes_have_the_documented_shape():
     buf, frame, sky = scenes.random_spheres(64, 36)
     assert len(buf.objects) == 485 and buf.n_blas == 2
     assert sky.shape == (128, 256, 4)
+
+
+def test_tlas_builder_choice_and_the_reference_builders_limit(oracle):
+    """The reference's TLAS builder overruns its 64-entry level arrays for some inputs of
+    more than about 1 300 objects; the producer refuses those instead, and offers the SAH
+    builder for any count."""
+    from raytracing_amd import scenes
+    with pytest.raises(H.HostError, match="64-entry"):
+        scenes.instanced_scene(32, 18, instances=1600, tris_per_blas=600)
+    buf, _, _ = scenes.instanced_scene(32, 18, instances=1600, tris_per_blas=600, tlas_tree=1)
+    assert len(buf.objects) == 1601
+    assert oracle.check_integrity(buf.tlas, len(buf.objects)) == 0
+    buf, _, _ = scenes.instanced_scene(32, 18, instances=1250, tris_per_blas=600)
+    assert oracle.check_integrity(buf.tlas, len(buf.objects)) == 0
