@@ -31,6 +31,8 @@ def build_workload(name, width, height, tree=0):
         return scenes.random_spheres(width, height, tree=tree), "random-spheres: floor + 484 instanced spheres (one 960-triangle BLAS)"
     if name == "mesh":
         return scenes.mesh_scene(width, height, tree=tree), "three procedural ~1M-triangle meshes + 4 quads"
+    if name == "instanced":
+        return scenes.instanced_scene(width, height), "1 250 instances of three ~40 k-triangle meshes (50 M instanced triangles) on a floor"
     if name == "few":
         return scenes.few_spheres(width, height), "few-sphere plumbing scene"
     raise SystemExit(f"unknown workload {name}")
@@ -148,15 +150,18 @@ def main():
             alg_bytes = 116 * c["nodes"] + 48 * c["tris"] + 180 * c["instances"] + 36 * c["hits"]
             alg_flops = 100 * c["nodes"] + 56 * c["tris"] + 30 * c["instances"]
             achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
-            traffic = None
+            # counters of the same launch, collected offline with rocprofv3 --pmc (tools/gpu_pmc.sh)
+            traffic, pmc_extra = None, None
             pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(pmc):
                 try:
                     rec = json.load(open(pmc))
                     if rec.get("workload") == args.workload and rec.get("spp") == args.spp and rec.get("width") == W:
                         traffic = rec.get("hbm_bytes_per_launch")
+                        pmc_extra = {k: rec[k] for k in ("simd_valu_issue_frac", "valu_lane_utilisation", "l2_hit_rate",
+                                                         "l1_accesses_per_cu_cycle") if k in rec}
                 except Exception:
-                    traffic = None
+                    traffic, pmc_extra = None, None
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                         "kernel": "rt::kFast<PT>", "kernel_ms": kernel_ms_avg,
@@ -166,7 +171,8 @@ def main():
                         "instances_per_ray": c["instances"] / max(1, c["rays"]),
                         "valu_tflops_algorithmic": alg_flops / (kernel_ms_avg * 1e-3) / 1e12,
                         "valu_frac_of_fp32_peak": alg_flops / (kernel_ms_avg * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                        "kernel_mrays_per_s": rays_per_launch_local / (kernel_ms_avg * 1e-3) / 1e6}
+                        "kernel_mrays_per_s": rays_per_launch_local / (kernel_ms_avg * 1e-3) / 1e6,
+                        "pmc_offline": pmc_extra}
         base = None
         if not args.no_cpu_baseline and world == 1:
             base = cpu_baseline(buf, frame, sky, W, Hh, args.spp, args.bounces, args.seed)

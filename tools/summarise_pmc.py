@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 --pmc passes written by tools/gpu_pmc.sh.
+
+    python tools/summarise_pmc.py <tag> [<tag> ...]  ->  JSON on stdout
+
+Reads gpurun_out/pmc_<tag>/*/**/*counter_collection.csv, sums every counter over the dispatches
+of the production kernel (rt::kFast<1, ...>, one launch per pass), and derives: HBM bytes per
+launch (FETCH_SIZE doubled — gfx950 reports half of wide reads — plus WRITE_SIZE, both in KiB),
+L2 hit rate, VALU lane utilisation and the share of cycles the SIMDs issue VALU work.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def summarise(tag):
+    acc = collections.defaultdict(float)
+    for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}", "*", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "rt::kFast<1" in row["Kernel_Name"]:
+                acc[row["Counter_Name"]] += float(row["Counter_Value"])
+    d = dict(sorted(acc.items()))
+    der = {}
+    if "FETCH_SIZE" in d:
+        der["hbm_bytes_per_launch_corrected"] = (2.0 * d["FETCH_SIZE"] + d.get("WRITE_SIZE", 0.0)) * 1024.0
+    if d.get("TCC_REQ_sum"):
+        der["l2_hit_rate"] = d["TCC_HIT_sum"] / (d["TCC_HIT_sum"] + d["TCC_MISS_sum"])
+    if d.get("SQ_ACTIVE_INST_VALU"):
+        # SQ_THREAD_CYCLES_VALU counts active lanes x quad-cycles; a full wave is 64 lanes
+        der["valu_lane_utilisation"] = d["SQ_THREAD_CYCLES_VALU"] / (64.0 * d["SQ_ACTIVE_INST_VALU"])
+        der["wave_cycles_waiting_frac"] = d["SQ_WAIT_ANY"] / d["SQ_WAVE_CYCLES"]
+    if d.get("GRBM_GUI_ACTIVE") and d.get("SQ_ACTIVE_INST_VALU"):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs issue one wave instruction per 4 cycles
+        cycles = d["GRBM_GUI_ACTIVE"] / 8.0
+        der["simd_valu_issue_frac"] = d["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles / 4.0)
+        der["l1_accesses_per_cu_cycle"] = d.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / (256.0 * cycles)
+    der["note"] = ("one launch of rt::kFast<PT> (bench.py --steps 1 --warmup 0); separate rocprofv3 --pmc passes; "
+                   "FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as read")
+    d["derived"] = der
+    return d
+
+
+if __name__ == "__main__":
+    print(json.dumps({t: summarise(t) for t in sys.argv[1:]}, indent=1))
