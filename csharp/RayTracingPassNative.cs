@@ -33,6 +33,8 @@ namespace Script.RayTracing
         [DllImport(Lib)] public static extern int rtamd_sky_upload(IntPtr ctx, void* rgba32f, int w, int h);
         [DllImport(Lib)] public static extern int rtamd_render(IntPtr ctx, FrameCBuffer* frame, ExtParams* ext, int w, int h, void* outRgba, void* outPrimId);
         [DllImport(Lib)] public static extern int rtamd_accum_reset(IntPtr ctx);
+        [DllImport(Lib)] public static extern int rtamd_composite_add(IntPtr ctx, void* srcRgba32f, void* dstRgba8, int w, int h);
+        [DllImport(Lib)] public static extern int rtamd_present(IntPtr ctx, void* srcRgba32f, void* dstRgba8, int w, int h, int tonemap, float exposure, float gamma);
     }
 
     // In BuildAccelerateStructureSystem.OnUpdate the eight ComputeBuffer.SetData calls (:124-158)
