@@ -88,11 +88,11 @@ def test_many_instances_tlas_larger_than_the_lds_copy(gpu_pass, oracle):
 
 
 @pytest.mark.parametrize("workload", ["spheres", "mesh"])
-def test_full_size_production_kernel_equals_reference_order_kernel(gpu_pass, workload):
-    """Benchmark-size scenes at 1920x1080, where the CPU oracle would take minutes: the
-    production kernel (rebuilt trees, nearest-first, LDS copies) and the reference-order kernel
-    (the caller's trees, the shader's visiting order) must agree on every pixel, bit for bit;
-    and a render split in tiles / shards must equal the whole."""
+def test_full_size_production_kernel_equals_reference_order_kernel(gpu_pass, oracle, workload):
+    """Benchmark-size scenes at 1920x1080 (2 spp, so that the CPU oracle finishes in seconds): the
+    production kernel (rebuilt trees, nearest-first, LDS copies), the reference-order kernel (the
+    caller's trees, the shader's visiting order) and the oracle must agree on every pixel, bit
+    for bit; and a render split in shards must equal the whole."""
     from raytracing_amd import scenes
     w, h = 1920, 1080
     buf, frame, sky = scenes.random_spheres(w, h) if workload == "spheres" else scenes.mesh_scene(w, h, target_tris=200_000)
@@ -105,6 +105,11 @@ def test_full_size_production_kernel_equals_reference_order_kernel(gpu_pass, wor
     assert _same(fast["t"], ref["t"])
     assert _same(fast["rgba"], ref["rgba"]), _report(workload, fast, ref)
     assert fast["rays"] == ref["rays"]
+    o = oracle.render(buf, frame, w, h, sky=sky, mode=1, spp=2, max_bounces=8, seed=77, nthreads=16)
+    assert _same(fast["ids"], o["ids"]), _report(workload, fast, o)
+    assert _same(fast["t"], o["t"])
+    assert _same(fast["rgba"], o["rgba"]), _report(workload, fast, o)
+    assert fast["rays"] == o["counters"]["rays"]
     # two interleaved shards compose to the same image
     parts = np.zeros_like(fast["rgba"])
     for r in range(2):
