@@ -76,6 +76,7 @@ struct FastScene {
     int32_t tlasRoot;            // index of the TLAS root in nodes
     // nodes kept in LDS by every workgroup: [0, hotTlas) and [blasBase, blasBase + hotBlas)
     int32_t hotTlas, blasBase, hotBlas;
+    int32_t* stackSpill;         // overflow of the LDS traversal stacks: [kSpillMax][threads of the grid]
 };
 
 template <typename T>
@@ -107,6 +108,7 @@ struct FastSceneHost {
     DBuf<FNrm> nrms;
     DBuf<int32_t> triOrig;
     DBuf<int32_t> superTiles;
+    DBuf<int32_t> stackSpill;
     DBuf<unsigned long long> stats;
     std::vector<int32_t> blasRoot;     // wide-node index of each BLAS root
     // node array: [0, tlasReserve) the TLAS of the last upload (breadth first), then every BLAS node,
@@ -123,7 +125,7 @@ struct FastSceneHost {
 
     void release() {
         nodes.release(); inst.release(); shade.release(); tris.release(); nrms.release(); triOrig.release();
-        superTiles.release(); stats.release();
+        superTiles.release(); stackSpill.release(); stats.release();
     }
 
     // Convert the nodes of a built tree; node i of the tree gets index remap[i].
@@ -362,6 +364,9 @@ constexpr int kLdsStack = 24;        // stack entries per lane, all in LDS: [ent
 constexpr int kHotNodes = 448;       // nodes every workgroup keeps in LDS (63 KiB): the TLAS and the top of the BLAS trees
 constexpr int kHotStride = 9;        // float4 per node in LDS: 144 bytes, so that piece j of 16 different nodes falls on 16 different bank groups
 constexpr int kModeRef = 0, kModePt = 1, kModePrimary = 2;
+constexpr int kNoInstance = -(1 << 24);
+constexpr int kSpillChunk = 12;      // entries moved between the LDS stack and its overflow area in HBM at a time
+constexpr int kSpillMax = 96;        // overflow entries per lane
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -472,7 +477,7 @@ __device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world
 // STATS = true builds a diagnostic variant that also counts, per phase, how often the wave
 // executed it and with how many active lanes (written to `stats`, 16 counters).
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene sc, Sky sky, RenderArgs a, int refillBelow, int nodeMin,
+__global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene sc, Sky sky, RenderArgs a, int refillBelow, int nodeMin, int stackLimit,
                                                        unsigned long long* stats) {
     unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define RT_STAT(slot, cond)                                                         \
@@ -490,6 +495,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
     // An inner-node test costs seven 16-byte loads per lane, each lane in its own 128-byte line, a
     // gather the vector cache serves one lane per cycle.  The nodes every ray passes through — the
     // TLAS and the first levels of the BLAS trees — are therefore read from an LDS copy.
+    const size_t gtid = (size_t)blockIdx.x * kBlockThreads + tid;
+    const size_t spillStride = (size_t)gridDim.x * kBlockThreads;
     const int hotTlas = sc.hotTlas, hotBlas = sc.hotBlas;
     for (int i = tid; i < (hotTlas + hotBlas) * 8; i += kBlockThreads) {
         const int n = i >> 3, c = i & 7;
@@ -519,21 +526,44 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
     float instNear = 0.0f;    // entry distance of the current instance's TLAS slot box
     int32_t node = 0;
     int sp = 0;
-    int instSp = -1;          // stack height on entering the current instance, -1 outside
+    int instSp = kNoInstance; // stack height on entering the current instance
+    int spilled = 0;          // entries of this lane's stack that were moved out to HBM (a multiple of kSpillChunk)
     int32_t curInst = -1;
     uint32_t rays = 0, pixRays = 0;   // ray segments of finished pixels / of the current pixel
 
+    int deepest = 0;          // STATS: largest stack height of this lane
 #define RT_PUSH(v)                                                        \
     do {                                                                  \
-        ldsStack[sp < kLdsStack ? sp : kLdsStack - 1][tid] = (v);         \
+        ldsStack[sp][tid] = (v);                                          \
         sp++;                                                             \
+        if (STATS && sp + spilled > deepest) deepest = sp + spilled;      \
     } while (0)
     // next stack entry; leaving an instance restores the world-space ray (.compute:377 returns)
 #define RT_POP()                                                          \
     do {                                                                  \
-        if (sp == instSp) { cur = world; curInst = -1; instSp = -1; }     \
+        if (sp == 0 && spilled != 0) {      /* rare: bring the last chunk back from HBM */ \
+            for (int i_ = 0; i_ < kSpillChunk; i_++)                      \
+                ldsStack[i_][tid] = sc.stackSpill[(size_t)(spilled - kSpillChunk + i_) * spillStride + gtid]; \
+            spilled -= kSpillChunk; sp = kSpillChunk; instSp += kSpillChunk; \
+        }                                                                 \
+        if (sp == instSp) { cur = world; curInst = -1; instSp = kNoInstance; } \
         if (sp == 0) { trav = false; node = 0; }                          \
-        else { sp--; node = ldsStack[sp < kLdsStack ? sp : kLdsStack - 1][tid]; } \
+        else { sp--; node = ldsStack[sp][tid]; }                          \
+    } while (0)
+    // Make room for the three pushes of a node step: a stack that is about to outgrow LDS moves its
+    // oldest kSpillChunk entries to HBM and slides the rest down (heights are kept relative to what is
+    // in LDS).  Rare: the deepest stack of the benchmark scenes is 14 to 23 entries.
+#define RT_MAKE_ROOM()                                                    \
+    do {                                                                  \
+        if (sp > stackLimit - 3) {                                        \
+            if (spilled + kSpillChunk > kSpillMax) { RT_REDO(); sp = 0; } \
+            else {                                                        \
+                for (int i_ = 0; i_ < kSpillChunk; i_++)                  \
+                    sc.stackSpill[(size_t)(spilled + i_) * spillStride + gtid] = ldsStack[i_][tid]; \
+                for (int i_ = kSpillChunk; i_ < sp; i_++) ldsStack[i_ - kSpillChunk][tid] = ldsStack[i_][tid]; \
+                spilled += kSpillChunk; sp -= kSpillChunk; instSp -= kSpillChunk; \
+            }                                                             \
+        }                                                                 \
     } while (0)
 
     // Hand the current pixel to the reference-order kernel: mark it, list it once, drop it.
@@ -660,7 +690,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                 world = next; cur = next;
                 best.t = RT_INF; best.inst = -1; best.tri = -1;
                 secondT = RT_INF; bestNear = 0.0f;
-                node = sc.tlasRoot; sp = 0; instSp = -1; curInst = -1;
+                node = sc.tlasRoot; sp = 0; instSp = kNoInstance; curInst = -1; spilled = 0;
                 trav = true;
                 pixRays++;
                 if (rayDegenerate(next)) RT_REDO();
@@ -706,13 +736,12 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                     const int nh = (d0 < RT_INF) + (d1 < RT_INF) + (d2 < RT_INF) + (d3 < RT_INF);
                     // nearest first: sort by entry distance (misses = +inf go last), push far to near
                     cswap(d0, c0, d1, c1); cswap(d2, c2, d3, c3); cswap(d0, c0, d2, c2); cswap(d1, c1, d3, c3); cswap(d1, c1, d2, c2);
+                    RT_MAKE_ROOM();
                     if (nh > 3) RT_PUSH(c3);
                     if (nh > 2) RT_PUSH(c2);
                     if (nh > 1) RT_PUSH(c1);
                     if (nh > 0) node = c0;
                     else RT_POP();
-                    // a ray that needs more stack than LDS holds goes to the reference-order kernel
-                    if (sp > kLdsStack) RT_REDO();
                 }
             }
             // B2: leaves
@@ -778,10 +807,16 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
     }
 #undef RT_PUSH
 #undef RT_POP
+#undef RT_MAKE_ROOM
 #undef RT_REDO
 #undef RT_STAT
-    if (STATS && lane == 0)
-        for (int i = 0; i < 16; i++) if (st_[i]) atomicAdd(stats + i, st_[i]);
+    if (STATS) {
+        for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(deepest, off, 64); deepest = o > deepest ? o : deepest; }
+        if (lane == 0) {
+            for (int i = 0; i < 15; i++) if (st_[i]) atomicAdd(stats + i, st_[i]);
+            atomicMax(stats + 15, (unsigned long long)deepest);
+        }
+    }
     unsigned long long r = rays;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off, 64);
@@ -790,6 +825,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
 
 struct FastLaunchConfig {
     int blocksPerCU = 1, refillBelow = 40, nodeMin = 12;
+    int stackLimit = kLdsStack;                 // LDS stack entries a lane may use before it moves a chunk to HBM (tests lower it)
     bool stats = false;
 };
 
@@ -798,6 +834,7 @@ inline FastLaunchConfig fastLaunchConfig() {
     if (const char* s = getenv("RTAMD_BLOCKS_PER_CU")) { int v = atoi(s); if (v > 0 && v <= 2) c.blocksPerCU = v; }
     if (const char* s = getenv("RTAMD_REFILL_BELOW")) { int v = atoi(s); if (v >= 1 && v <= 64) c.refillBelow = v; }
     if (const char* s = getenv("RTAMD_NODE_MIN")) { int v = atoi(s); if (v >= 1 && v <= 64) c.nodeMin = v; }
+    if (const char* s = getenv("RTAMD_STACK_LIMIT")) { int v = atoi(s); if (v >= kSpillChunk + 4 && v <= kLdsStack) c.stackLimit = v; }
     if (const char* s = getenv("RTAMD_STATS")) c.stats = atoi(s) != 0;
     return c;
 }
@@ -835,6 +872,8 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
     sc.nodes = fs.nodes.p; sc.inst = fs.inst.p; sc.shade = fs.shade.p;
     sc.tris = fs.tris.p; sc.nrms = fs.nrms.p; sc.triOrig = fs.triOrig.p; sc.superTiles = fs.superTiles.p; sc.nSuperTiles = (int)fs.hSuper.size();
     sc.tlasRoot = fs.tlasRoot;
+    if ((e = fs.stackSpill.ensure((size_t)kSpillMax * (size_t)(numCU * cfg.blocksPerCU) * kBlockThreads)) != hipSuccess) return e;
+    sc.stackSpill = fs.stackSpill.p;
     // LDS budget: the whole TLAS if it leaves half of the room (or more, when the BLAS trees are small) to the BLAS tops
     {
         const int nb = fs.nBlasNodes < (size_t)kHotNodes ? (int)fs.nBlasNodes : kHotNodes;
@@ -849,7 +888,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         // identity of the un-jittered primary hit: a separate, uncounted pass
         RenderArgs ids = a;
         ids.outRgba = nullptr; ids.accum = nullptr; ids.spp = 1;
-        hipLaunchKernelGGL((kFast<kModePrimary, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, ids, cfg.refillBelow, cfg.nodeMin, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((kFast<kModePrimary, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, ids, cfg.refillBelow, cfg.nodeMin, cfg.stackLimit, (unsigned long long*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         // the work-queue head and ray counter are shared: reset them between the passes
         if ((e = hipMemsetAsync(a.rayCount, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
@@ -858,7 +897,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         // diagnostic build: per-phase execution counts and active lanes, printed to stderr
         if ((e = fs.stats.ensure(16)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(fs.stats.p, 0, 16 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL((kFast<kModePt, true>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, fs.stats.p);
+        hipLaunchKernelGGL((kFast<kModePt, true>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.stackLimit, fs.stats.p);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         unsigned long long h[16];
         if ((e = hipMemcpyAsync(h, fs.stats.p, sizeof(h), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
@@ -866,12 +905,13 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         const char* names[8] = {"phaseA", "nodeStep", "instEnter", "triLeaf", "triTest", "-", "leafPhase(trav lanes)", "nodeLoop(trav lanes)"};
         for (int i = 0; i < 8; i++)
             if (h[2 * i]) fprintf(stderr, "[rtamd stats] %-22s executions %12llu  mean active lanes %6.2f\n", names[i], h[2 * i], (double)h[2 * i + 1] / (double)h[2 * i]);
+        fprintf(stderr, "[rtamd stats] deepest traversal stack %llu of %d entries\n", h[15], kLdsStack);
         return hipSuccess;
     }
     if (a.mode == RTAMD_MODE_PT)
-        hipLaunchKernelGGL((kFast<kModePt, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((kFast<kModePt, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.stackLimit, (unsigned long long*)nullptr);
     else
-        hipLaunchKernelGGL((kFast<kModeRef, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((kFast<kModeRef, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.stackLimit, (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 

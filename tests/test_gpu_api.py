@@ -223,9 +223,9 @@ def test_error_codes(scene_few):
     p.Dispose()
 
 
-def test_deep_tree_falls_back_to_the_reference_order_kernel(gpu_pass, oracle):
-    """A degenerate chain-shaped BLAS needs more stack than the production kernel keeps in
-    LDS: the library must notice and still return the reference's image."""
+def test_deep_chain_shaped_tree(gpu_pass, oracle):
+    """A degenerate chain-shaped BLAS makes the reference's own stack grow past 100 entries;
+    the library (which rebuilds the tree above the triangles) must return the reference's image."""
     n = 200
     mesh = H.Mesh.quad()
     # quads stacked along +z, facing +z (winding and normals flipped), seen from the far end
@@ -277,3 +277,20 @@ def test_deep_tree_falls_back_to_the_reference_order_kernel(gpu_pass, oracle):
     gpu_pass.SetSkyBox(None)
     g = gpu_pass.Execute(frame, 32, 32, out_rgba=True, out_prim_id=True, mode=T.MODE_REF)
     assert np.array_equal(g["ids"], o["ids"]) and np.array_equal(g["rgba"], o["rgba"])
+
+
+def test_traversal_stack_overflow_area(gpu_pass, oracle, scene_mesh_small, monkeypatch):
+    """With the LDS part of the traversal stack cut to 16 entries, rays of the mesh scene move
+    chunks of their stack to the overflow area in HBM and back; the image must not change."""
+    buf, frame, sky = scene_mesh_small
+    w, h = 96, 54
+    gpu_pass.SetScene(buf)
+    gpu_pass.SetSkyBox(sky)
+    kw = dict(mode=T.MODE_PT, spp=4, max_bounces=4, seed=1234)
+    o = oracle.render(buf, frame, w, h, sky=sky, mode=1, spp=4, max_bounces=4, seed=1234)
+    monkeypatch.setenv("RTAMD_STACK_LIMIT", "16")
+    g = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, **kw)
+    monkeypatch.delenv("RTAMD_STACK_LIMIT")
+    assert np.array_equal(g["ids"], o["ids"]) and np.array_equal(g["t"], o["t"], equal_nan=True)
+    assert np.array_equal(g["rgba"], o["rgba"])
+    assert g["rays"] == o["counters"]["rays"]
