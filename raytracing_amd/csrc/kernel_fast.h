@@ -495,8 +495,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
     // An inner-node test costs seven 16-byte loads per lane, each lane in its own 128-byte line, a
     // gather the vector cache serves one lane per cycle.  The nodes every ray passes through — the
     // TLAS and the first levels of the BLAS trees — are therefore read from an LDS copy.
-    const size_t gtid = (size_t)blockIdx.x * kBlockThreads + tid;
-    const size_t spillStride = (size_t)gridDim.x * kBlockThreads;
+    // (index into the stack overflow area; formed where it is needed so that it holds no registers)
+#define RT_SPILL_AT(entry) sc.stackSpill[(size_t)(entry) * ((size_t)gridDim.x * kBlockThreads) + ((size_t)blockIdx.x * kBlockThreads + tid)]
     const int hotTlas = sc.hotTlas, hotBlas = sc.hotBlas;
     for (int i = tid; i < (hotTlas + hotBlas) * 8; i += kBlockThreads) {
         const int n = i >> 3, c = i & 7;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
     do {                                                                  \
         if (sp == 0 && spilled != 0) {      /* rare: bring the last chunk back from HBM */ \
             for (int i_ = 0; i_ < kSpillChunk; i_++)                      \
-                ldsStack[i_][tid] = sc.stackSpill[(size_t)(spilled - kSpillChunk + i_) * spillStride + gtid]; \
+                ldsStack[i_][tid] = RT_SPILL_AT(spilled - kSpillChunk + i_); \
             spilled -= kSpillChunk; sp = kSpillChunk; instSp += kSpillChunk; \
         }                                                                 \
         if (sp == instSp) { cur = world; curInst = -1; instSp = kNoInstance; } \
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
             if (spilled + kSpillChunk > kSpillMax) { RT_REDO(); sp = 0; } \
             else {                                                        \
                 for (int i_ = 0; i_ < kSpillChunk; i_++)                  \
-                    sc.stackSpill[(size_t)(spilled + i_) * spillStride + gtid] = ldsStack[i_][tid]; \
+                    RT_SPILL_AT(spilled + i_) = ldsStack[i_][tid];       \
                 for (int i_ = kSpillChunk; i_ < sp; i_++) ldsStack[i_ - kSpillChunk][tid] = ldsStack[i_][tid]; \
                 spilled += kSpillChunk; sp -= kSpillChunk; instSp -= kSpillChunk; \
             }                                                             \
@@ -808,6 +808,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
 #undef RT_PUSH
 #undef RT_POP
 #undef RT_MAKE_ROOM
+#undef RT_SPILL_AT
 #undef RT_REDO
 #undef RT_STAT
     if (STATS) {
