@@ -30,7 +30,7 @@
 //
 // Layout (arrays 128-byte aligned in HBM; a lane's node is exactly one 128-byte line):
 //   WNode  128 B  lx,hx,ly,hy,lz,hz (float4 = the four children), child[4], pad;
-//                 BLAS nodes first, the TLAS nodes appended behind them
+//                 the TLAS in front (breadth first, one slot per object reserved), then the BLAS nodes level by level
 //   FTri    64 B  (lo.xyz,hi.x)(hi.yz,rank,v0.x)(v0.yz,e1.xy)(e1.z,e2.xyz) — leaf order of the new tree;
 //                 rank = position in the reference's visiting order
 //   FNrm    48 B  n0,n1,n2, indexed by rank                  — read once per closest hit
@@ -470,10 +470,10 @@ __device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world
 //     least `nodeMin` lanes still have inner nodes to test, then all leaves are handled
 //     together (a per-round vote between node / triangle / instance steps measured 8 % slower);
 //   * the wave draws pixels from one global counter, 8x8 pixel tiles first.
-// The traversal stack lives in LDS ([entry][thread], one bank per lane).  A pixel with a ray
-// that needs more than kLdsStack entries, or with a ray that could meet 0 * inf in a slab
-// test, is dropped unfinished and listed for the reference-order kernel, which the host runs
-// over that list afterwards.
+// The traversal stack lives in LDS ([entry][thread], one bank per lane) and overflows in chunks
+// into HBM.  A pixel with a ray that could meet 0 * inf in a slab test, with an order-ambiguous
+// hit, or with a stack beyond LDS plus the overflow area is dropped unfinished and listed for the
+// reference-order kernel, which the host runs over that list afterwards.
 // STATS = true builds a diagnostic variant that also counts, per phase, how often the wave
 // executed it and with how many active lanes (written to `stats`, 16 counters).
 template <int MODE, bool STATS>
