@@ -468,7 +468,9 @@ __device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world
 //     traversing, then shade / start new rays / fetch new pixels together;
 //   * inside traversal, lanes that reached a leaf (triangles or an instance) wait while at
 //     least `nodeMin` lanes still have inner nodes to test, then all leaves are handled
-//     together (a per-round vote between node / triangle / instance steps measured 8 % slower);
+//     together (a per-round vote between node / triangle / instance steps measured 8 % slower),
+//     except that a small group of instance entries next to a large group of triangle leaves (or
+//     the reverse) waits for a later leaf phase;
 //   * the wave draws pixels from one global counter, 8x8 pixel tiles first.
 // The traversal stack lives in LDS ([entry][thread], one bank per lane) and overflows in chunks
 // into HBM.  A pixel with a ray that could meet 0 * inf in a slab test, with an order-ambiguous
@@ -477,8 +479,8 @@ __device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world
 // STATS = true builds a diagnostic variant that also counts, per phase, how often the wave
 // executed it and with how many active lanes (written to `stats`, 16 counters).
 template <int MODE, bool STATS>
-__global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene sc, Sky sky, RenderArgs a, int refillBelow, int nodeMin, int stackLimit,
-                                                       unsigned long long* stats) {
+__global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene sc, Sky sky, RenderArgs a, int refillBelow, int nodeMin, int leafGroupMin,
+                                                       int stackLimit, unsigned long long* stats) {
     unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define RT_STAT(slot, cond)                                                         \
     do {                                                                            \
@@ -745,10 +747,20 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                 }
             }
             // B2: leaves
-            RT_STAT(2, trav && node < 0 && ((uint32_t)~node & kInstanceBit));
-            RT_STAT(3, trav && node < 0 && !((uint32_t)~node & kInstanceBit));
+            // Instance entries and triangle leaves are different code: when one of the two groups is
+            // small (< leafGroupMin lanes) and the other is not, the small one sits this phase out and
+            // joins a later, fuller one.
+            bool doLeaf = trav && node < 0;
+            {
+                const bool isInst = doLeaf && ((uint32_t)~node & kInstanceBit);
+                const int ni = __popcll(__ballot(isInst)), nt = __popcll(__ballot(doLeaf && !isInst));
+                if (ni > 0 && ni < leafGroupMin && nt >= leafGroupMin) doLeaf = doLeaf && !isInst;
+                else if (nt > 0 && nt < leafGroupMin && ni >= leafGroupMin) doLeaf = doLeaf && isInst;
+            }
+            RT_STAT(2, doLeaf && ((uint32_t)~node & kInstanceBit));
+            RT_STAT(3, doLeaf && !((uint32_t)~node & kInstanceBit));
             RT_STAT(6, trav);
-            if (trav && node < 0) {
+            if (doLeaf) {
                 const uint32_t code = (uint32_t)~node;
                 if (code & kInstanceBit) {
                     // enter an instance (.compute:279-287)
@@ -825,7 +837,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
 }
 
 struct FastLaunchConfig {
-    int blocksPerCU = 1, refillBelow = 40, nodeMin = 12;
+    int blocksPerCU = 1, refillBelow = 40, nodeMin = 12, leafGroupMin = 20;
     int stackLimit = kLdsStack;                 // LDS stack entries a lane may use before it moves a chunk to HBM (tests lower it)
     bool stats = false;
 };
@@ -835,6 +847,7 @@ inline FastLaunchConfig fastLaunchConfig() {
     if (const char* s = getenv("RTAMD_BLOCKS_PER_CU")) { int v = atoi(s); if (v > 0 && v <= 2) c.blocksPerCU = v; }
     if (const char* s = getenv("RTAMD_REFILL_BELOW")) { int v = atoi(s); if (v >= 1 && v <= 64) c.refillBelow = v; }
     if (const char* s = getenv("RTAMD_NODE_MIN")) { int v = atoi(s); if (v >= 1 && v <= 64) c.nodeMin = v; }
+    if (const char* s = getenv("RTAMD_LEAF_GROUP_MIN")) { int v = atoi(s); if (v >= 0 && v <= 64) c.leafGroupMin = v; }
     if (const char* s = getenv("RTAMD_STACK_LIMIT")) { int v = atoi(s); if (v >= kSpillChunk + 4 && v <= kLdsStack) c.stackLimit = v; }
     if (const char* s = getenv("RTAMD_STATS")) c.stats = atoi(s) != 0;
     return c;
@@ -889,7 +902,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         // identity of the un-jittered primary hit: a separate, uncounted pass
         RenderArgs ids = a;
         ids.outRgba = nullptr; ids.accum = nullptr; ids.spp = 1;
-        hipLaunchKernelGGL((kFast<kModePrimary, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, ids, cfg.refillBelow, cfg.nodeMin, cfg.stackLimit, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((kFast<kModePrimary, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, ids, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         // the work-queue head and ray counter are shared: reset them between the passes
         if ((e = hipMemsetAsync(a.rayCount, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
@@ -898,7 +911,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         // diagnostic build: per-phase execution counts and active lanes, printed to stderr
         if ((e = fs.stats.ensure(16)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(fs.stats.p, 0, 16 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL((kFast<kModePt, true>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.stackLimit, fs.stats.p);
+        hipLaunchKernelGGL((kFast<kModePt, true>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, fs.stats.p);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         unsigned long long h[16];
         if ((e = hipMemcpyAsync(h, fs.stats.p, sizeof(h), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
@@ -910,9 +923,9 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         return hipSuccess;
     }
     if (a.mode == RTAMD_MODE_PT)
-        hipLaunchKernelGGL((kFast<kModePt, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.stackLimit, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((kFast<kModePt, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
     else
-        hipLaunchKernelGGL((kFast<kModeRef, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.stackLimit, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((kFast<kModeRef, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 
