@@ -837,7 +837,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
 }
 
 struct FastLaunchConfig {
-    int blocksPerCU = 1, refillBelow = 40, nodeMin = 12, leafGroupMin = 20;
+    // refillBelow / nodeMin = 0: chosen per scene in launchFast
+    int blocksPerCU = 1, refillBelow = 0, nodeMin = 0, leafGroupMin = 20;
     int stackLimit = kLdsStack;                 // LDS stack entries a lane may use before it moves a chunk to HBM (tests lower it)
     bool stats = false;
 };
@@ -851,6 +852,16 @@ inline FastLaunchConfig fastLaunchConfig() {
     if (const char* s = getenv("RTAMD_STACK_LIMIT")) { int v = atoi(s); if (v >= kSpillChunk + 4 && v <= kLdsStack) c.stackLimit = v; }
     if (const char* s = getenv("RTAMD_STATS")) c.stats = atoi(s) != 0;
     return c;
+}
+
+// Regrouping thresholds.  With every inner node in LDS a node step waits for nothing, and small
+// batches cost little: shade early (refillBelow 32), keep stepping nodes with few lanes (nodeMin 8).
+// A scene whose lower levels live in L2 / HBM pays a memory round trip per node step, which larger
+// batches amortise (48 / 16).  Measured optima of the spheres, mesh and instanced benchmark scenes.
+inline void chooseThresholds(FastLaunchConfig& cfg, const FastSceneHost& fs) {
+    const bool allHot = fs.nBlasNodes + (size_t)fs.nTlasNodes <= (size_t)kHotNodes;
+    if (cfg.refillBelow == 0) cfg.refillBelow = allHot ? 32 : 48;
+    if (cfg.nodeMin == 0) cfg.nodeMin = allHot ? 8 : 16;
 }
 
 inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs& a, hipStream_t stream) {
@@ -875,7 +886,8 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
         numCU = prop.multiProcessorCount;
     }
-    const FastLaunchConfig cfg = fastLaunchConfig();
+    FastLaunchConfig cfg = fastLaunchConfig();
+    chooseThresholds(cfg, fs);
     long long wavesNeeded = ((long long)fs.hSuper.size() * 1024 + 63) / 64;
     long long blocksNeeded = (wavesNeeded + kBlockThreads / 64 - 1) / (kBlockThreads / 64);
     int grid = numCU * cfg.blocksPerCU;
