@@ -735,14 +735,14 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                              ox, oy, oz, ix, iy, iz, cullT, d2, d3);
                     int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
                     // (empty slots carry an all-+inf box: their entry distance is +inf, a miss)
-                    const int nh = (d0 < RT_INF) + (d1 < RT_INF) + (d2 < RT_INF) + (d3 < RT_INF);
                     // nearest first: sort by entry distance (misses = +inf go last), push far to near
                     cswap(d0, c0, d1, c1); cswap(d2, c2, d3, c3); cswap(d0, c0, d2, c2); cswap(d1, c1, d3, c3); cswap(d1, c1, d2, c2);
                     RT_MAKE_ROOM();
-                    if (nh > 3) RT_PUSH(c3);
-                    if (nh > 2) RT_PUSH(c2);
-                    if (nh > 1) RT_PUSH(c1);
-                    if (nh > 0) node = c0;
+                    // (sorted: the misses, +inf, are last)
+                    if (d3 < RT_INF) RT_PUSH(c3);
+                    if (d2 < RT_INF) RT_PUSH(c2);
+                    if (d1 < RT_INF) RT_PUSH(c1);
+                    if (d0 < RT_INF) node = c0;
                     else RT_POP();
                 }
             }
