@@ -718,7 +718,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                     // separate conditionals with ds_read / global_load they need more registers and run slower)
                     float4 lx, hx, ly, hy, lz, hz, chf;
                     if (hot >= 0) {
-                        const float4* lp = ldsNodes + hot * kHotStride;
+                        const float4* lp = ldsNodes + __umul24(hot, kHotStride);   // (24-bit multiply: full rate)
                         lx = lp[0]; hx = lp[1]; ly = lp[2]; hy = lp[3]; lz = lp[4]; hz = lp[5]; chf = lp[6];
                     } else {
                         const float4* np = reinterpret_cast<const float4*>(sc.nodes + node);
