@@ -544,7 +544,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
 #define RT_POP()                                                          \
     do {                                                                  \
         if (sp == 0 && spilled != 0) {      /* rare: bring the last chunk back from HBM */ \
-            for (int i_ = 0; i_ < kSpillChunk; i_++)                      \
+            _Pragma("unroll 1") for (int i_ = 0; i_ < kSpillChunk; i_++)  \
                 ldsStack[i_][tid] = RT_SPILL_AT(spilled - kSpillChunk + i_); \
             spilled -= kSpillChunk; sp = kSpillChunk; instSp += kSpillChunk; \
         }                                                                 \
@@ -560,9 +560,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
         if (sp > stackLimit - 3) {                                        \
             if (spilled + kSpillChunk > kSpillMax) { RT_REDO(); sp = 0; } \
             else {                                                        \
-                for (int i_ = 0; i_ < kSpillChunk; i_++)                  \
+                _Pragma("unroll 1") for (int i_ = 0; i_ < kSpillChunk; i_++) \
                     RT_SPILL_AT(spilled + i_) = ldsStack[i_][tid];       \
-                for (int i_ = kSpillChunk; i_ < sp; i_++) ldsStack[i_ - kSpillChunk][tid] = ldsStack[i_][tid]; \
+                _Pragma("unroll 1") for (int i_ = kSpillChunk; i_ < sp; i_++) ldsStack[i_ - kSpillChunk][tid] = ldsStack[i_][tid]; \
                 spilled += kSpillChunk; sp -= kSpillChunk; instSp -= kSpillChunk; \
             }                                                             \
         }                                                                 \
