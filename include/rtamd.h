@@ -202,6 +202,11 @@ int rtamd_set_stream(rtamd_ctx* ctx, void* hip_stream);
  * segments it traced. */
 int rtamd_last_render_stats(const rtamd_ctx* ctx, float* kernel_ms, uint64_t* ray_segments);
 
+/* The part of that time spent in the hand-over pass (pixels the production kernel
+ * could not settle itself and gave to the reference-order kernel), and how many
+ * pixels that was.  No counterpart in the reference. */
+int rtamd_last_handover_stats(const rtamd_ctx* ctx, float* handover_ms, int32_t* pixels);
+
 /* Presentation step of the reference: AddShader's `Blend SrcAlpha One`
  * (Assets/Shaders/AddShader.shader:11,43-46) onto an 8-bit UNORM target
  * (RayTracingPass.cs:58): dst = saturate(dst + src.rgb * src.a), quantised to

@@ -90,7 +90,7 @@ struct rtamd_ctx {
     DevBuf<int32_t> redoList, redoCount;
     DevBuf<float4> redoSamples;
     int32_t lastRedoPixels = 0;
-    float lastKernelMs = 0.f;
+    float lastKernelMs = 0.f, lastHandoverMs = 0.f;
     uint64_t lastRays = 0;
 };
 
@@ -391,7 +391,7 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
     rt::DevCounters hc;
     unsigned long long hr[2] = {0, 0};
     int32_t herr = 0, redo = 0;
-    float ms = 0.f;
+    float ms = 0.f, handoverMs = 0.f;
     const size_t maskWords = (npix + 31) / 32;
     HIP_TRY(c, c->redoMask.alloc(maskWords));
     HIP_TRY(c, c->redoList.alloc(npix));
@@ -443,8 +443,10 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipEventElapsedTime(&ms2, c->evStart, c->evStop));
         ms += ms2;
+        handoverMs = ms2;
     }
     c->lastRedoPixels = redo;
+    c->lastHandoverMs = handoverMs;
     if (getenv("RTAMD_VERBOSE"))
         fprintf(stderr, "[rtamd] render %dx%d mode %d: %.3f ms, %d pixels handed to the reference-order kernel; nodes %zu (BLAS %zu), depth BLAS %d TLAS %d, instances %d\n",
                 width, height, a.mode, ms, redo, c->fast.hNodes.size(), c->fast.nBlasNodes, c->fast.maxDepth, c->fast.tlasDepth, c->fast.nInst);
@@ -463,6 +465,13 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
         oc->max_blas_stack = hc.maxBlasStack; oc->max_tlas_stack = hc.maxTlasStack; oc->reserved = hc.overflow;
     }
     if (herr & 1) return fail(c, RTAMD_ERR_STACK_OVERFLOW, "traversal stack overflow (scene deeper than the shader's stacks allow)");
+    return RTAMD_OK;
+}
+
+int rtamd_last_handover_stats(const rtamd_ctx* c, float* ms, int32_t* pixels) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (ms) *ms = c->lastHandoverMs;
+    if (pixels) *pixels = c->lastRedoPixels;
     return RTAMD_OK;
 }
 
