@@ -117,3 +117,49 @@ def test_full_size_production_kernel_equals_reference_order_kernel(gpu_pass, ora
         gpu_pass.Execute(frame, w, h, out_rgba=part, shard_rank=r, shard_count=2, **kw)
         parts += part
     assert _same(parts, fast["rgba"])
+
+
+def _tie_scene(w, h):
+    """Geometry made to produce exact ties and near-ties: coincident instances (same mesh, same
+    transform), a mesh with every triangle stored twice plus zero-area triangles, coplanar
+    overlapping quads, and a second sphere mesh shifted by a hair."""
+    from raytracing_amd import host as H, scenes
+    sys_ = H.BuildAccelerateStructureSystem()
+    sph = H.Mesh.uv_sphere(24, 12, 0.5)
+    doubled = H.Mesh(sph.positions, sph.normals,
+                     np.concatenate([sph.indices, sph.indices, np.repeat(sph.indices[:40, :1], 3, axis=1)]))   # twice + degenerate
+    b_sph = sys_.BakeBLAS(sph)
+    b_dbl = sys_.BakeBLAS(doubled)
+    b_quad = sys_.BakeBLAS(H.Mesh.quad())
+    rot = H.quat_axis_angle((1, 0, 0), 90.0)
+    sys_.AddEntity(b_quad, H.trs((0, 0, 0), rot, (30, 30, 1)), albedo=(0.7, 0.7, 0.7), specular=(0.05, 0.05, 0.05))
+    sys_.AddEntity(b_quad, H.trs((0.3, 0, 0.2), rot, (10, 10, 1)), albedo=(0.2, 0.7, 0.2), specular=(0.05, 0.05, 0.05))   # coplanar, overlapping
+    for k, x in enumerate((-1.5, 0.0, 1.5)):
+        m = H.trs((x, 0.5, 0.0), s=(1, 1, 1))
+        sys_.AddEntity(b_sph, m, albedo=(0.8, 0.3, 0.2), specular=(0.1, 0.1, 0.1))
+        sys_.AddEntity(b_sph, m, albedo=(0.2, 0.3, 0.8), specular=(0.6, 0.6, 0.6))          # coincident instance
+        sys_.AddEntity(b_dbl, H.trs((x, 0.5, 1.4)), albedo=(0.9, 0.9, 0.2), specular=(0.3, 0.3, 0.3))
+        sys_.AddEntity(b_sph, H.trs((x + 1e-6, 0.5, 1.4)), albedo=(0.3, 0.9, 0.9), specular=(0.0, 0.0, 0.0))   # a hair away
+    sys_.AddEntity(b_quad, H.trs((0, 4.0, 0.5), H.quat_axis_angle((1, 0, 0), -90.0), (3, 3, 1)), albedo=(0, 0, 0), specular=(0, 0, 0), emission=(2, 2, 2))
+    buf = sys_.OnUpdate()
+    sys_.close()
+    frame = scenes.look_at_camera((0.2, 2.2, -6.0), (0.0, 0.4, 0.6), 40.0, w, h)
+    return buf, frame, scenes.procedural_sky()
+
+
+def test_exact_ties_and_near_ties(gpu_pass, oracle):
+    """Coincident instances, duplicated and zero-area triangles, coplanar quads: the winner must be
+    the one the reference's visiting order gives, in the production kernel as in the oracle."""
+    w, h = 160, 90
+    buf, frame, sky = _tie_scene(w, h)
+    gpu_pass.SetScene(buf)
+    gpu_pass.SetSkyBox(sky)
+    for mode, kw in ((T.MODE_REF, {}), (T.MODE_PT, dict(spp=4, max_bounces=5, seed=5))):
+        g = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, mode=mode, **kw)
+        o = oracle.render(buf, frame, w, h, sky=sky, mode=mode, spp=kw.get("spp", 1), max_bounces=kw.get("max_bounces", 0),
+                          seed=kw.get("seed", 0), nthreads=8)
+        assert _same(g["ids"], o["ids"]), _report("ties", g, o)
+        assert _same(g["t"], o["t"])
+        assert _same(g["rgba"], o["rgba"]), _report("ties", g, o)
+        assert g["rays"] == o["counters"]["rays"]
+    assert len(np.unique(o["ids"][..., 0])) > 8
