@@ -205,3 +205,46 @@ def instanced_scene(width=1920, height=1080, instances=1250, tris_per_blas=40_00
     sys.close()
     frame = look_at_camera((0.0, 14.0, -side * 1.4), (0.0, 0.0, 0.0), 40.0, width, height)
     return buf, frame, procedural_sky()
+
+
+def random_soup(width=640, height=360, seed=0, meshes=4, tris_per_mesh=600, instances=40):
+    """Stress scene for parity campaigns: triangle soups (random sizes, slivers, shared vertices, a few
+    zero-area triangles) instanced with random rotations, non-uniform and mirrored scales, at
+    coordinates from 1e-2 to 1e3; random mix of diffuse / mirror / emissive materials."""
+    rs = np.random.RandomState(1000 + seed)
+    sys = H.BuildAccelerateStructureSystem(tlas_tree=int(rs.randint(0, 2)))
+    blas = []
+    for m in range(meshes):
+        nt = int(rs.randint(tris_per_mesh // 4, tris_per_mesh + 1))
+        nv = max(3, nt // 2)
+        pos = rs.normal(0, 1, size=(nv, 3)).astype(np.float32)
+        pos *= np.float32(10.0 ** rs.uniform(-1, 1))
+        idx = rs.randint(0, nv, size=(nt, 3)).astype(np.int32)
+        near = rs.rand(nt) < 0.6                      # mostly small triangles: neighbours in a shuffled ring
+        ring = rs.permutation(nv).astype(np.int32)
+        base = rs.randint(0, nv, size=nt)
+        idx[near] = np.stack([ring[base[near]], ring[(base[near] + 1) % nv], ring[(base[near] + 2) % nv]], 1)
+        idx[: nt // 50, 1] = idx[: nt // 50, 0]       # zero-area triangles
+        nrm = pos / np.maximum(np.linalg.norm(pos, axis=1, keepdims=True), 1e-6)
+        blas.append(sys.BakeBLAS(H.Mesh(pos, nrm.astype(np.float32), idx), int(rs.randint(0, 2))))
+    world = float(10.0 ** rs.uniform(0.5, 3.0))
+    for i in range(instances):
+        q = H.quat_axis_angle(rs.normal(size=3) + 1e-3, float(rs.uniform(0, 360)))
+        s = (10.0 ** rs.uniform(-1.0, 0.5, size=3)) * world * 0.05
+        if rs.rand() < 0.3:
+            s[int(rs.randint(0, 3))] *= -1.0         # mirrored instance
+        t = rs.uniform(-0.5, 0.5, size=3) * world
+        kind = rs.rand()
+        if kind < 0.6:
+            mat = dict(albedo=tuple(rs.uniform(0.2, 0.9, 3)), specular=(0.04, 0.04, 0.04))
+        elif kind < 0.85:
+            mat = dict(albedo=(0, 0, 0), specular=tuple(rs.uniform(0.5, 1.0, 3)))
+        else:
+            mat = dict(albedo=(0, 0, 0), specular=(0, 0, 0), emission=tuple(rs.uniform(0.5, 3.0, 3)))
+        sys.AddEntity(blas[int(rs.randint(0, meshes))], H.trs(tuple(t), q, tuple(s)), **mat)
+    buf = sys.OnUpdate()
+    sys.close()
+    ang = rs.uniform(0, 2 * np.pi)
+    eye = np.array([np.cos(ang), rs.uniform(-0.3, 0.6), np.sin(ang)]) * world * rs.uniform(0.2, 1.4)
+    frame = look_at_camera(tuple(eye), tuple(rs.uniform(-0.1, 0.1, 3) * world), float(rs.uniform(30, 80)), width, height)
+    return buf, frame, procedural_sky()

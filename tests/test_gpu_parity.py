@@ -163,3 +163,20 @@ def test_exact_ties_and_near_ties(gpu_pass, oracle):
         assert _same(g["rgba"], o["rgba"]), _report("ties", g, o)
         assert g["rays"] == o["counters"]["rays"]
     assert len(np.unique(o["ids"][..., 0])) > 8
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_triangle_soups(gpu_pass, oracle, seed):
+    """Random soups (slivers, zero-area triangles, shared vertices) under rotated, non-uniformly
+    scaled and mirrored instances at coordinates from 1e-2 to 1e3, TLAS and BLAS from either builder."""
+    from raytracing_amd import scenes
+    w, h = 128, 72
+    buf, frame, sky = scenes.random_soup(w, h, seed=seed)
+    gpu_pass.SetScene(buf)
+    gpu_pass.SetSkyBox(sky)
+    g = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, mode=T.MODE_PT, spp=3, max_bounces=6, seed=seed)
+    o = oracle.render(buf, frame, w, h, sky=sky, mode=1, spp=3, max_bounces=6, seed=seed, nthreads=8)
+    assert _same(g["ids"], o["ids"]), _report("soup", g, o)
+    assert _same(g["t"], o["t"])
+    assert _same(g["rgba"], o["rgba"]), _report("soup", g, o)
+    assert g["rays"] == o["counters"]["rays"]

@@ -17,6 +17,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracing_amd import backend, scenes, types as T  # noqa: E402
 
 
+def compare(rt, wl, ci, frame, w, h, spp):
+    kw = dict(mode=T.MODE_PT, spp=spp, max_bounces=8, seed=1000 + ci)
+    a = rt.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, **kw)
+    b = rt.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, flags=T.FLAG_REFERENCE_ORDER, **kw)
+    ids = int((a["ids"] != b["ids"]).any(-1).sum())
+    tt = int(((a["t"] != b["t"]) & ~(np.isnan(a["t"]) & np.isnan(b["t"]))).sum())
+    rgba = int(((a["rgba"] != b["rgba"]) & ~(np.isnan(a["rgba"]) & np.isnan(b["rgba"]))).any(-1).sum())
+    rays = a["rays"] != b["rays"]
+    cover = float((b["ids"][..., 0] >= 0).mean())
+    print(f"{wl} camera {ci}: coverage {cover:.2f}, {b['rays']} segments, {a['handover_pixels']} pixels handed over; "
+          f"mismatching ids {ids}, t {tt}, radiance pixels {rgba}, ray count {'DIFFERS' if rays else 'equal'}", flush=True)
+    return ids + tt + rgba + int(rays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cameras", type=int, default=6)
@@ -30,6 +44,14 @@ def main():
     rs = np.random.RandomState(2025)
     bad_total = 0
     for wl in args.workloads.split(","):
+        if wl == "soup":
+            # a new random scene per "camera"
+            for ci in range(args.cameras):
+                buf, frame, sky = scenes.random_soup(w, h, seed=ci)
+                rt.SetScene(buf)
+                rt.SetSkyBox(sky)
+                bad_total += compare(rt, wl, ci, frame, w, h, args.spp)
+            continue
         if wl == "spheres":
             buf, frame0, sky = scenes.random_spheres(w, h)
             centre, radius = np.array([0.0, 0.5, 0.0]), 18.0
@@ -49,16 +71,7 @@ def main():
                 eye = centre + radius * rs.uniform(0.3, 1.2) * np.array([np.cos(ang), 0.0, np.sin(ang)]) + np.array([0, rs.uniform(0.3, 8.0), 0])
                 tgt = centre + rs.uniform(-2, 2, size=3) * np.array([1, 0.2, 1])
                 frame = scenes.look_at_camera(tuple(eye), tuple(tgt), float(rs.uniform(25, 70)), w, h)
-            kw = dict(mode=T.MODE_PT, spp=args.spp, max_bounces=8, seed=1000 + ci)
-            a = rt.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, **kw)
-            b = rt.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, flags=T.FLAG_REFERENCE_ORDER, **kw)
-            ids = int((a["ids"] != b["ids"]).any(-1).sum())
-            tt = int((a["t"] != b["t"]).sum())
-            rgba = int((a["rgba"] != b["rgba"]).any(-1).sum())
-            rays = a["rays"] != b["rays"]
-            cover = float((b["ids"][..., 0] >= 0).mean())
-            print(f"{wl} camera {ci}: coverage {cover:.2f}, {b['rays']} segments; mismatching ids {ids}, t {tt}, radiance pixels {rgba}, ray count {'DIFFERS' if rays else 'equal'}", flush=True)
-            bad_total += ids + tt + rgba + int(rays)
+            bad_total += compare(rt, wl, ci, frame, w, h, args.spp)
     print("total mismatches", bad_total)
     return 1 if bad_total else 0
 
