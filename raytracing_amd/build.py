@@ -36,7 +36,7 @@ def _run(cmd):
 
 def build_device(force=False):
     src = os.path.join(CSRC, "rtamd.hip")
-    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     deps += [os.path.join(INC, "rtamd.h")]
     out = os.path.join(LIB, "librtamd.so")
     if force or _newer(out, deps):

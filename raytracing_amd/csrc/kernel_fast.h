@@ -701,121 +701,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
         if (__ballot(trav) == 0ull) break;   // nobody got a ray: every lane is out of work
 
         // ------------------------------------------------ phase B: traversal
-        for (;;) {
-            // B1: inner nodes, for as long as enough lanes have one
-            for (;;) {
-                const bool atNode = trav && node >= 0;
-                const unsigned long long nm = __ballot(atNode);
-                if (nm == 0ull) break;
-                if (__popcll(nm) < nodeMin && __ballot(trav && node < 0) != 0ull) break;
-                RT_STAT(1, atNode);
-                RT_STAT(7, trav);
-                if (atNode) {
-                    int hot = -1;
-                    if (node < hotTlas) hot = node;
-                    else if ((uint32_t)(node - sc.blasBase) < (uint32_t)hotBlas) hot = hotTlas + (node - sc.blasBase);
-                    // (written as if / else the two cases compile to one generic-address load per piece; as two
-                    // separate conditionals with ds_read / global_load they need more registers and run slower)
-                    float4 lx, hx, ly, hy, lz, hz, chf;
-                    if (hot >= 0) {
-                        const float4* lp = ldsNodes + __umul24(hot, kHotStride);   // (24-bit multiply: full rate)
-                        lx = lp[0]; hx = lp[1]; ly = lp[2]; hy = lp[3]; lz = lp[4]; hz = lp[5]; chf = lp[6];
-                    } else {
-                        const float4* np = reinterpret_cast<const float4*>(sc.nodes + node);
-                        lx = np[0]; hx = np[1]; ly = np[2]; hy = np[3]; lz = np[4]; hz = np[5]; chf = np[6];
-                    }
-                    const int4 ch = make_int4(__float_as_int(chf.x), __float_as_int(chf.y), __float_as_int(chf.z), __float_as_int(chf.w));
-                    const f2 ox = {cur.origin.x, cur.origin.x}, oy = {cur.origin.y, cur.origin.y}, oz = {cur.origin.z, cur.origin.z};
-                    const f2 ix = {cur.invDir.x, cur.invDir.x}, iy = {cur.invDir.y, cur.invDir.y}, iz = {cur.invDir.z, cur.invDir.z};
-                    float d0, d1, d2, d3;
-                    const float cullT = best.t * RT_CULL_RELAX;
-                    slabPair(f2{lx.x, lx.y}, f2{hx.x, hx.y}, f2{ly.x, ly.y}, f2{hy.x, hy.y}, f2{lz.x, lz.y}, f2{hz.x, hz.y},
-                             ox, oy, oz, ix, iy, iz, cullT, d0, d1);
-                    slabPair(f2{lx.z, lx.w}, f2{hx.z, hx.w}, f2{ly.z, ly.w}, f2{hy.z, hy.w}, f2{lz.z, lz.w}, f2{hz.z, hz.w},
-                             ox, oy, oz, ix, iy, iz, cullT, d2, d3);
-                    int32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-                    // (empty slots carry an all-+inf box: their entry distance is +inf, a miss)
-                    // nearest first: sort by entry distance (misses = +inf go last), push far to near
-                    cswap(d0, c0, d1, c1); cswap(d2, c2, d3, c3); cswap(d0, c0, d2, c2); cswap(d1, c1, d3, c3); cswap(d1, c1, d2, c2);
-                    RT_MAKE_ROOM();
-                    // (sorted: the misses, +inf, are last)
-                    if (d3 < RT_INF) RT_PUSH(c3);
-                    if (d2 < RT_INF) RT_PUSH(c2);
-                    if (d1 < RT_INF) RT_PUSH(c1);
-                    if (d0 < RT_INF) node = c0;
-                    else RT_POP();
-                }
-            }
-            // B2: leaves
-            // Instance entries and triangle leaves are different code: when one of the two groups is
-            // small (< leafGroupMin lanes) and the other is not, the small one sits this phase out and
-            // joins a later, fuller one.
-            bool doLeaf = trav && node < 0;
-            {
-                const bool isInst = doLeaf && ((uint32_t)~node & kInstanceBit);
-                const int ni = __popcll(__ballot(isInst)), nt = __popcll(__ballot(doLeaf && !isInst));
-                if (ni > 0 && ni < leafGroupMin && nt >= leafGroupMin) doLeaf = doLeaf && !isInst;
-                else if (nt > 0 && nt < leafGroupMin && ni >= leafGroupMin) doLeaf = doLeaf && isInst;
-            }
-            RT_STAT(2, doLeaf && ((uint32_t)~node & kInstanceBit));
-            RT_STAT(3, doLeaf && !((uint32_t)~node & kInstanceBit));
-            RT_STAT(6, trav);
-            if (doLeaf) {
-                const uint32_t code = (uint32_t)~node;
-                if (code & kInstanceBit) {
-                    // enter an instance (.compute:279-287)
-                    const int rank = (int)(code & (kInstanceBit - 1u));
-                    const FInst fi = sc.inst[rank];
-                    instNear = slabNear(fi.b0.x, fi.b0.w, fi.b0.y, fi.bhy, fi.b0.z, fi.bhz, world);
-                    cur = makeRay(rowsPoint(fi.r0, fi.r1, fi.r2, world.origin), rowsDir(fi.r0, fi.r1, fi.r2, world.direction));
-                    instSp = sp;
-                    node = fi.root;
-                    curInst = rank;
-                    if (rayDegenerate(cur)) RT_REDO();
-                } else {
-                    const uint32_t start = code >> 2;
-                    const int cnt = (int)(code & 3u) + 1;
-                    const float tEntry = best.t * RT_CULL_RELAX;   // the reference masks all four slots before testing any (:298)
-                    uint32_t mask = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (k < cnt) {
-                            const float4* tp = reinterpret_cast<const float4*>(sc.tris + start + k);
-                            const float4 A = tp[0], B = tp[1];
-                            if (slabHit(A.x, A.w, A.y, B.x, A.z, B.y, cur, tEntry)) mask |= 1u << k;
-                        }
-                    }
-                    for (;;) {
-                        RT_STAT(4, mask != 0);
-                        if (!mask) break;
-                        const int k = __ffs(mask) - 1;
-                        mask &= mask - 1u;
-                        const float4* tp = reinterpret_cast<const float4*>(sc.tris + start + k);
-                        const float4 B = tp[1], C = tp[2], D = tp[3];
-                        float t, u, v;
-                        if (trisect(cur.origin, cur.direction, v3(B.w, C.x, C.y), v3(C.z, C.w, D.x), v3(D.y, D.z, D.w), t, u, v)) {
-                            const int32_t ti = __float_as_int(B.z);
-                            const bool closer = t < best.t;
-                            const bool tie = t == best.t && (curInst < best.inst || (curInst == best.inst && ti < best.tri));
-                            if (closer || tie) {
-                                const float4 A = tp[0];
-                                secondT = fmin_(secondT, best.t);
-                                bestNear = fmax_(slabNear(A.x, A.w, A.y, B.x, A.z, B.y, cur), instNear);
-                                best.t = t; best.u = u; best.v = v; best.inst = curInst; best.tri = ti;
-                            } else secondT = fmin_(secondT, t);
-                        }
-                    }
-                    RT_POP();
-                }
-            }
-            const unsigned long long tm = __ballot(trav);
-            if (tm == 0ull) break;
-            if (__popcll(tm) < refillBelow) {
-                // leave only if some waiting lane can actually be given a new ray
-                const bool canRefill = !trav && !(noMoreWork && !pixelActive && !pathActive);
-                if (__ballot(canRefill) != 0ull) break;
-            }
-        }
+#define RT_CAN_REFILL (!trav && !(noMoreWork && !pixelActive && !pathActive))
+#include "traverse_body.inc"
+#undef RT_CAN_REFILL
     }
 #undef RT_PUSH
 #undef RT_POP
