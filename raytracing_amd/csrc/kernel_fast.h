@@ -497,8 +497,6 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
     // An inner-node test costs seven 16-byte loads per lane, each lane in its own 128-byte line, a
     // gather the vector cache serves one lane per cycle.  The nodes every ray passes through — the
     // TLAS and the first levels of the BLAS trees — are therefore read from an LDS copy.
-    // (index into the stack overflow area; formed where it is needed so that it holds no registers)
-#define RT_SPILL_AT(entry) sc.stackSpill[(size_t)(entry) * ((size_t)gridDim.x * kBlockThreads) + ((size_t)blockIdx.x * kBlockThreads + tid)]
     const int hotTlas = sc.hotTlas, hotBlas = sc.hotBlas;
     for (int i = tid; i < (hotTlas + hotBlas) * 8; i += kBlockThreads) {
         const int n = i >> 3, c = i & 7;
@@ -534,39 +532,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
     uint32_t rays = 0, pixRays = 0;   // ray segments of finished pixels / of the current pixel
 
     int deepest = 0;          // STATS: largest stack height of this lane
-#define RT_PUSH(v)                                                        \
-    do {                                                                  \
-        ldsStack[sp][tid] = (v);                                          \
-        sp++;                                                             \
-        if (STATS && sp + spilled > deepest) deepest = sp + spilled;      \
-    } while (0)
-    // next stack entry; leaving an instance restores the world-space ray (.compute:377 returns)
-#define RT_POP()                                                          \
-    do {                                                                  \
-        if (sp == 0 && spilled != 0) {      /* rare: bring the last chunk back from HBM */ \
-            _Pragma("unroll 1") for (int i_ = 0; i_ < kSpillChunk; i_++)  \
-                ldsStack[i_][tid] = RT_SPILL_AT(spilled - kSpillChunk + i_); \
-            spilled -= kSpillChunk; sp = kSpillChunk; instSp += kSpillChunk; \
-        }                                                                 \
-        if (sp == instSp) { cur = world; curInst = -1; instSp = kNoInstance; } \
-        if (sp == 0) { trav = false; node = 0; }                          \
-        else { sp--; node = ldsStack[sp][tid]; }                          \
-    } while (0)
-    // Make room for the three pushes of a node step: a stack that is about to outgrow LDS moves its
-    // oldest kSpillChunk entries to HBM and slides the rest down (heights are kept relative to what is
-    // in LDS).  Rare: the deepest stack of the benchmark scenes is 14 to 23 entries.
-#define RT_MAKE_ROOM()                                                    \
-    do {                                                                  \
-        if (sp > stackLimit - 3) {                                        \
-            if (spilled + kSpillChunk > kSpillMax) { RT_REDO(); sp = 0; } \
-            else {                                                        \
-                _Pragma("unroll 1") for (int i_ = 0; i_ < kSpillChunk; i_++) \
-                    RT_SPILL_AT(spilled + i_) = ldsStack[i_][tid];       \
-                _Pragma("unroll 1") for (int i_ = kSpillChunk; i_ < sp; i_++) ldsStack[i_ - kSpillChunk][tid] = ldsStack[i_][tid]; \
-                spilled += kSpillChunk; sp -= kSpillChunk; instSp -= kSpillChunk; \
-            }                                                             \
-        }                                                                 \
-    } while (0)
+#define RT_WORLD_RAY() world
+#include "traverse_macros.inc"
 
     // Hand the current pixel to the reference-order kernel: mark it, list it once, drop it.
 #define RT_REDO()                                                                   \
@@ -709,6 +676,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
 #undef RT_POP
 #undef RT_MAKE_ROOM
 #undef RT_SPILL_AT
+#undef RT_WORLD_RAY
 #undef RT_REDO
 #undef RT_STAT
     if (STATS) {
@@ -727,6 +695,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
 struct FastLaunchConfig {
     // refillBelow / nodeMin = 0: chosen per scene in launchFast
     int blocksPerCU = 1, refillBelow = 0, nodeMin = 0, leafGroupMin = 20;
+    bool pool = false;                          // PT mode through kPool (more paths than lanes) instead of kFast
     int stackLimit = kLdsStack;                 // LDS stack entries a lane may use before it moves a chunk to HBM (tests lower it)
     bool stats = false;
 };
@@ -738,6 +707,7 @@ inline FastLaunchConfig fastLaunchConfig() {
     if (const char* s = getenv("RTAMD_NODE_MIN")) { int v = atoi(s); if (v >= 1 && v <= 64) c.nodeMin = v; }
     if (const char* s = getenv("RTAMD_LEAF_GROUP_MIN")) { int v = atoi(s); if (v >= 0 && v <= 64) c.leafGroupMin = v; }
     if (const char* s = getenv("RTAMD_STACK_LIMIT")) { int v = atoi(s); if (v >= kSpillChunk + 4 && v <= kLdsStack) c.stackLimit = v; }
+    if (const char* s = getenv("RTAMD_PIPELINE")) c.pool = strcmp(s, "pool") == 0;
     if (const char* s = getenv("RTAMD_STATS")) c.stats = atoi(s) != 0;
     return c;
 }

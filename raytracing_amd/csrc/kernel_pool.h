@@ -1,0 +1,464 @@
+// Path-tracing kernel with more paths than lanes (opt-in: RTAMD_PIPELINE=pool).
+//
+// kFast keeps one path per lane, so hit shading, sky shading, sample bookkeeping and camera-ray
+// generation all run inside the traversal kernel with whatever lanes happen to need them (about a
+// third of the wave each), and that code is 40 % of the kernel's instructions.  Here a wave owns
+// kPoolSlots paths, each in a 128-byte record in HBM (L2 / Infinity-Cache resident: 24 KiB per
+// wave).  A lane only traverses: when its ray is done it writes the hit into the path's record,
+// queues the path for shading (a per-wave queue in LDS) and takes the next ready ray from a second
+// per-wave queue.  When 64 hits have collected, the whole wave shades them — one path per lane,
+// all 64 lanes busy, traversal state of the lanes untouched — and queues the follow-up rays;
+// finished paths are replaced on the spot by new (pixel, sample) pairs.  The queues are private
+// to a wave, so there is no synchronisation, no waiting and nothing to deadlock on.
+//
+// A finished sample's radiance goes to a sample buffer; kPoolSum adds each pixel's samples in
+// sample order afterwards, so the image is bit-identical to kFast's and the oracle's.
+#pragma once
+
+#include "kernel_fast.h"
+
+namespace rt {
+
+struct alignas(128) PoolRec {
+    float4 r0;            // origin.xyz, direction.x
+    float4 r1;            // direction.yz, invDir.xy
+    float invz;           // invDir.z
+    uint32_t pix;         // y * width + x
+    uint32_t key;         // RNG key of (seed, pixel, sample)
+    int32_t bounce;       // index of the segment the ray belongs to
+    float4 hit;           // t, u, v, triangle rank (bits)
+    int32_t inst;         // instance rank; kPoolMiss; kPoolUnsettled: hand the pixel over; kPoolFresh: no path yet
+    uint32_t path;        // index of the path in the batch's sample buffer
+    int32_t pad0[2];
+    float4 energy;        // throughput
+    float4 L;             // radiance gathered so far
+    float4 pad1;
+};
+static_assert(sizeof(PoolRec) == 128, "one record per 128-byte line");
+
+constexpr int32_t kPoolMiss = -1, kPoolUnsettled = -3, kPoolFresh = -4;
+constexpr int kPoolSlots = 192;      // paths per wave
+constexpr int kPoolQueue = 256;      // entries per queue (power of two >= kPoolSlots)
+constexpr int kPoolChunk = 512;      // path indices a wave takes from the batch at a time
+constexpr int kPoolHotNodes = 320;   // LDS: 96 KiB stacks + 16 KiB queues + 45 KiB nodes
+
+struct PoolBatch {
+    PoolRec* recs;                // [waves of the grid][kPoolSlots]
+    float4* sampleL;              // [sample in batch][work item]: radiance, segment count (bits)
+    float4* runSum;               // [work item]: running sum, segment count (bits)
+    unsigned long long* next;     // next path of the batch to hand out
+    uint32_t nWork;               // work items = 1024 * super-tiles of this chunk
+    int32_t superBase;            // first super-tile of the chunk in FastScene::superTiles
+    int32_t sampleBase;           // first sample of the batch (relative to sample_offset)
+    int32_t nSamples;             // samples in the batch
+    int32_t firstBatch, lastBatch;
+    int32_t hotTlas, hotBlas;     // hot-node ranges for kPoolHotNodes
+};
+
+// work item -> pixel; false when the item lies outside the image or the requested rectangle
+__device__ __forceinline__ bool poolPixel(const FastScene& sc, const RenderArgs& a, const PoolBatch& b, uint32_t w, int& x, int& y) {
+    const int st = sc.superTiles[b.superBase + (int)(w >> 10)];
+    const int within = (int)(w & 1023u);
+    const int tilesX = (a.width + 31) / 32;
+    const int sx = st % tilesX, sy = st / tilesX;
+    const int t8 = within >> 6, p8 = within & 63;
+    x = sx * 32 + (t8 & 3) * 8 + (p8 & 7);
+    y = sy * 32 + (t8 >> 2) * 8 + (p8 >> 3);
+    return x < a.width && y < a.height && x >= a.tileX && y >= a.tileY && x < a.tileX + a.tileW && y < a.tileY + a.tileH;
+}
+
+__device__ __forceinline__ void poolHandOver(const RenderArgs& a, uint32_t p) {
+    const uint32_t bit = 1u << (p & 31u);
+    const uint32_t old = atomicOr(a.redoMask + (p >> 5), bit);
+    if (!(old & bit)) {
+        const int i = atomicAdd(a.redoCount, 1);
+        if (i < a.redoCap) a.redoList[i] = (int32_t)p;
+        else atomicOr(a.errorFlag, 4);
+    }
+}
+
+__device__ __forceinline__ Ray poolLoadRay(const PoolRec* rec) {
+    const float4 r0 = rec->r0, r1 = rec->r1;
+    const float iz = rec->invz;
+    Ray r;
+    r.origin = v3(r0.x, r0.y, r0.z);
+    r.direction = v3(r0.w, r1.x, r1.y);
+    r.invDir = v3(r1.z, r1.w, iz);
+    return r;
+}
+
+__global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene sc, Sky sky, RenderArgs a, PoolBatch b, int refillBelow,
+                                                                       int nodeMin, int leafGroupMin, int stackLimit, int poolSlots) {
+    constexpr bool STATS = false;
+#define RT_STAT(slot, cond) do { } while (0)
+    __shared__ int32_t ldsStack[kLdsStack][kBlockThreads];
+    __shared__ float4 ldsNodes[kPoolHotNodes * kHotStride];
+    __shared__ uint16_t ldsQueues[kBlockThreads / 64][2][kPoolQueue];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    uint16_t* const rayQ = ldsQueues[wave][0];     // paths with a ray ready to traverse
+    uint16_t* const hitQ = ldsQueues[wave][1];     // paths whose ray has been traversed (or that need a first ray)
+    PoolRec* const recs = b.recs + ((size_t)blockIdx.x * (kBlockThreads / 64) + wave) * kPoolSlots;
+    const unsigned long long totalPaths = (unsigned long long)b.nWork * (unsigned long long)b.nSamples;
+    const unsigned long long laneBelow = (1ull << lane) - 1ull;
+
+    const int hotTlas = b.hotTlas, hotBlas = b.hotBlas;
+    for (int i = tid; i < (hotTlas + hotBlas) * 8; i += kBlockThreads) {
+        const int n = i >> 3, c = i & 7;
+        const int g = n < hotTlas ? n : sc.blasBase + (n - hotTlas);
+        if (c < 7) ldsNodes[n * kHotStride + c] = reinterpret_cast<const float4*>(sc.nodes + g)[c];
+    }
+    __syncthreads();
+
+    // the same in every lane of the wave
+    int rayHead = 0, rayTail = 0, hitHead = 0, hitTail = 0;
+    int nAlloc = 0;               // record slots handed out so far
+    unsigned long long pathNext = 0, pathEnd = 0;   // the wave's current chunk of path indices
+    bool noMoreWork = false;
+
+    // lane state
+    bool trav = false, unsettled = false;
+    int32_t slot = -1;            // the path this lane traverses
+    Ray world = makeRay(v3(0, 0, 0), v3(0, 0, 1));
+    Ray cur = world;
+    FastHit best;
+    best.t = RT_INF; best.u = best.v = 0; best.inst = -1; best.tri = -1;
+    float secondT = RT_INF, bestNear = 0.0f, instNear = 0.0f;
+    int32_t node = 0;
+    int sp = 0;
+    int instSp = kNoInstance;
+    int spilled = 0;
+    int32_t curInst = -1;
+    int deepest = 0;
+    (void)deepest;
+#define RT_WORLD_RAY() world
+#include "traverse_macros.inc"
+    // a ray that cannot be settled here: its pixel goes to the reference-order kernel (when the path is shaded)
+#define RT_REDO() do { unsettled = true; trav = false; } while (0)
+
+    for (;;) {
+        // ---------------------------------------- finished lanes publish their hits
+        {
+            const bool fin = !trav && slot >= 0;
+            const unsigned long long m = __ballot(fin);
+            if (fin) {
+                PoolRec* rec = recs + slot;
+                const bool amb = best.t < RT_INF && secondT < bestNear;   // order-dependent in the reference: see kernel_fast.h
+                rec->hit = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
+                rec->inst = (unsettled || amb) ? kPoolUnsettled : best.inst;
+                hitQ[(hitTail + __popcll(m & laneBelow)) & (kPoolQueue - 1)] = (uint16_t)slot;
+                slot = -1;
+            }
+            hitTail += __popcll(m);
+            __threadfence_block();      // records and queue entries are read by other lanes of the wave below
+        }
+        // ---------------------------------------- shade 64 queued paths at a time, all lanes busy
+        for (;;) {
+            const int idle = __popcll(__ballot(!trav));
+            const int hitCnt = hitTail - hitHead, rayCnt = rayTail - rayHead;
+            int nShade = 0;
+            if (hitCnt >= 64 || (hitCnt > 0 && rayCnt < idle)) nShade = hitCnt < 64 ? hitCnt : 64;
+            int nNew = 0;     // unused lanes of the pass start brand-new paths while record slots are left
+            if (!noMoreWork && nAlloc < poolSlots && (nShade > 0 || rayCnt < idle)) {
+                nNew = 64 - nShade;
+                if (nNew > poolSlots - nAlloc) nNew = poolSlots - nAlloc;
+            }
+            if (nShade + nNew == 0) break;
+            __builtin_amdgcn_wave_barrier();
+            int32_t s = -1;
+            if (lane < nShade) s = hitQ[(hitHead + lane) & (kPoolQueue - 1)];
+            else if (lane < nShade + nNew) s = nAlloc + (lane - nShade);
+            hitHead += nShade;
+            nAlloc += nNew;
+
+            bool goOn = false, ended = false;
+            if (s >= 0) {
+                PoolRec* rec = recs + s;
+                // (the whole record at once: one round trip)
+                const int32_t instRec = rec->inst;
+                const float4 meta = *reinterpret_cast<const float4*>(&rec->invz);
+                const float4 r0 = rec->r0, r1 = rec->r1, e4 = rec->energy, l4 = rec->L, h4 = rec->hit;
+                const int32_t inst = lane < nShade ? instRec : kPoolFresh;
+                if (inst == kPoolFresh) ended = true;
+                else {
+                    const uint32_t pix = __float_as_uint(meta.y), key = __float_as_uint(meta.z);
+                    const int bounce = __float_as_int(meta.w);
+                    if (inst == kPoolUnsettled) { poolHandOver(a, pix); ended = true; }
+                    else {
+                        Ray w;
+                        w.origin = v3(r0.x, r0.y, r0.z);
+                        w.direction = v3(r0.w, r1.x, r1.y);
+                        w.invDir = v3(r1.z, r1.w, meta.x);
+                        V3 energy = v3(e4.x, e4.y, e4.z), L = v3(l4.x, l4.y, l4.z);
+                        bool write = true;
+                        if (inst >= 0) {
+                            FastHit h;
+                            h.t = h4.x; h.u = h4.y; h.v = h4.z; h.inst = inst; h.tri = __float_as_int(h4.w);
+                            const Surf sf = resolveHit(sc, w, h);
+                            L = L + energy * sf.emission;
+                            V3 dir;
+                            if (bounce < a.maxBounces && scatter(sf.albedo, sf.specular, sf.normal, w.direction, key, (uint32_t)bounce, energy, dir)) {
+                                const Ray next = makeRay(sf.position + sf.normal * 0.001f, dir);
+                                write = false;
+                                if (rayDegenerate(next)) { poolHandOver(a, pix); ended = true; }
+                                else {
+                                    rec->r0 = make_float4(next.origin.x, next.origin.y, next.origin.z, next.direction.x);
+                                    rec->r1 = make_float4(next.direction.y, next.direction.z, next.invDir.x, next.invDir.y);
+                                    *reinterpret_cast<float4*>(&rec->invz) = make_float4(next.invDir.z, meta.y, meta.z, __int_as_float(bounce + 1));
+                                    rec->energy = make_float4(energy.x, energy.y, energy.z, 0.f);
+                                    rec->L = make_float4(L.x, L.y, L.z, 0.f);
+                                    goOn = true;
+                                }
+                            }
+                        } else {
+                            L = L + energy * shadeMiss(sky, w.direction);
+                        }
+                        if (write) {
+                            b.sampleL[rec->path] = make_float4(L.x, L.y, L.z, __int_as_float(bounce + 1));
+                            ended = true;
+                        }
+                    }
+                }
+            }
+            // finished (and brand-new) paths: the record takes the next (pixel, sample) of the batch
+            bool fresh = false;      // the record holds a fresh placeholder that has to come round again
+            {
+                const unsigned long long me = __ballot(ended);
+                if (me != 0ull && !noMoreWork) {
+                    // path indices come in chunks of kPoolChunk per wave (one atomic per chunk); a lane
+                    // that finds the chunk used up keeps a placeholder and asks again in the next pass
+                    if (pathNext == pathEnd) {
+                        unsigned long long got = 0;
+                        if (lane == 0) got = atomicAdd(b.next, (unsigned long long)kPoolChunk);
+                        got = __shfl(got, 0, 64);
+                        if (got >= totalPaths) noMoreWork = true;
+                        else { pathNext = got; pathEnd = totalPaths - got < (unsigned long long)kPoolChunk ? totalPaths : got + kPoolChunk; }
+                    }
+                    const unsigned long long base = pathNext;
+                    const unsigned long long avail = pathEnd - pathNext;
+                    const unsigned long long wantN = (unsigned long long)__popcll(me);
+                    pathNext += wantN < avail ? wantN : avail;
+                    if (ended) {
+                        const unsigned long long p = base + (unsigned long long)__popcll(me & laneBelow);
+                        if (noMoreWork) { }
+                        else if (p >= pathEnd) { recs[s].inst = kPoolFresh; fresh = true; }
+                        else {
+                            PoolRec* rec = recs + s;
+                            const uint32_t wItem = (uint32_t)(p % b.nWork);
+                            const int smp = (int)(p / b.nWork);
+                            bool live = false;
+                            int x, y;
+                            if (poolPixel(sc, a, b, wItem, x, y)) {
+                                const uint32_t pix = (uint32_t)y * (uint32_t)a.width + (uint32_t)x;
+                                if (!((a.redoMask[pix >> 5] >> (pix & 31u)) & 1u)) {
+                                    const uint32_t key = rngKey(a.seedHi, a.seedLo, pix, (uint32_t)(a.sampleOffset + b.sampleBase + smp));
+                                    float jx = a.cb.PixelOffset[0], jy = a.cb.PixelOffset[1];
+                                    if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
+                                    const Ray r = cameraRay(a.cb, pixelToNdc(x, jx, a.invWidth), pixelToNdc(y, jy, a.invHeight));
+                                    if (rayDegenerate(r)) poolHandOver(a, pix);
+                                    else {
+                                        rec->r0 = make_float4(r.origin.x, r.origin.y, r.origin.z, r.direction.x);
+                                        rec->r1 = make_float4(r.direction.y, r.direction.z, r.invDir.x, r.invDir.y);
+                                        *reinterpret_cast<float4*>(&rec->invz) = make_float4(r.invDir.z, __uint_as_float(pix), __uint_as_float(key), __int_as_float(0));
+                                        rec->path = (uint32_t)p;
+                                        rec->energy = make_float4(1.f, 1.f, 1.f, 0.f);
+                                        rec->L = make_float4(0.f, 0.f, 0.f, 0.f);
+                                        live = true;
+                                    }
+                                }
+                            }
+                            if (live) goOn = true;
+                            else { rec->inst = kPoolFresh; fresh = true; }     // no such path: take another one next time
+                        }
+                    }
+                }
+            }
+            // queue the paths that have a ray to traverse; placeholders go back to the shading queue
+            {
+                const unsigned long long mg = __ballot(goOn);
+                if (goOn) rayQ[(rayTail + __popcll(mg & laneBelow)) & (kPoolQueue - 1)] = (uint16_t)s;
+                rayTail += __popcll(mg);
+                const unsigned long long mf = __ballot(fresh);
+                if (fresh) hitQ[(hitTail + __popcll(mf & laneBelow)) & (kPoolQueue - 1)] = (uint16_t)s;
+                hitTail += __popcll(mf);
+            }
+            __threadfence_block();
+        }
+        // ---------------------------------------- idle lanes take the next ready rays
+        {
+            const bool idleLane = !trav;
+            const unsigned long long m = __ballot(idleLane);
+            const int rayCnt = rayTail - rayHead;
+            const int want = __popcll(m);
+            const int k = want < rayCnt ? want : rayCnt;
+            const int mine = __popcll(m & laneBelow);
+            if (idleLane && mine < k) {
+                slot = rayQ[(rayHead + mine) & (kPoolQueue - 1)];
+                world = poolLoadRay(recs + slot);
+                cur = world;
+                best.t = RT_INF; best.u = best.v = 0; best.inst = -1; best.tri = -1;
+                secondT = RT_INF; bestNear = 0.0f;
+                node = sc.tlasRoot; sp = 0; instSp = kNoInstance; curInst = -1; spilled = 0;
+                unsettled = false;
+                trav = true;
+            }
+            rayHead += k;
+        }
+        if (__ballot(trav) == 0ull) {
+            // nothing to traverse: more shading / new paths, or (both queues empty, no work left) the end
+            if (hitTail - hitHead == 0 && rayTail - rayHead == 0) break;
+            continue;
+        }
+        // a lane is served when it has a hit to publish
+#define RT_CAN_REFILL (!trav && slot >= 0)
+#include "traverse_body.inc"
+#undef RT_CAN_REFILL
+    }
+#undef RT_PUSH
+#undef RT_POP
+#undef RT_MAKE_ROOM
+#undef RT_SPILL_AT
+#undef RT_WORLD_RAY
+#undef RT_REDO
+#undef RT_STAT
+}
+
+// Adds the batch's samples to each pixel's running sum, in sample order; the last batch writes
+// the pixel and counts its ray segments.
+__global__ __launch_bounds__(256) void kPoolSum(FastScene sc, RenderArgs a, PoolBatch b) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long rays = 0;
+    if (w < b.nWork) {
+        int x, y;
+        if (poolPixel(sc, a, b, w, x, y)) {
+            float4 run = b.firstBatch ? make_float4(0.f, 0.f, 0.f, 0.f) : b.runSum[w];
+            V3 sum = v3(run.x, run.y, run.z);
+            uint32_t segs = __float_as_uint(run.w);
+            for (int s = 0; s < b.nSamples; s++) {
+                const float4 v = b.sampleL[(size_t)s * b.nWork + w];
+                sum = sum + v3(v.x, v.y, v.z);
+                segs += __float_as_uint(v.w);
+            }
+            if (b.lastBatch) {
+                const uint32_t pix = (uint32_t)y * (uint32_t)a.width + (uint32_t)x;
+                if (!((a.redoMask[pix >> 5] >> (pix & 31u)) & 1u)) {
+                    writePathPixel(a, pix, sum);
+                    rays = segs;
+                }
+            } else {
+                b.runSum[w] = make_float4(sum.x, sum.y, sum.z, __uint_as_float(segs));
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rays += __shfl_xor(rays, off, 64);
+    if ((threadIdx.x & 63) == 0 && rays) atomicAdd(a.rayCount, rays);
+}
+
+struct PoolHost {
+    DBuf<PoolRec> recs;
+    DBuf<float4> sampleL, runSum;
+    void release() { recs.release(); sampleL.release(); runSum.release(); }
+};
+
+inline size_t poolMaxPaths() {
+    size_t cap = (size_t)1 << 27;
+    if (const char* s = getenv("RTAMD_POOL_MAX_PATHS")) { long long v = atoll(s); if (v >= 1024) cap = (size_t)v; }
+    return cap;
+}
+
+// PT-mode render of the pixels selected by `a` (radiance only: the identity of the primary
+// hit comes from kFast<kModePrimary>, launched here first when asked for).
+inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, const RenderArgs& a, hipStream_t stream) {
+    int tilesX = (a.width + 31) / 32;
+    fs.hSuper.clear();
+    int sx0 = a.tileX / 32, sx1 = (a.tileX + a.tileW - 1) / 32, sy0 = a.tileY / 32, sy1 = (a.tileY + a.tileH - 1) / 32;
+    for (int sy = sy0; sy <= sy1; sy++)
+        for (int sx = sx0; sx <= sx1; sx++) {
+            int id = sy * tilesX + sx;
+            if (a.shardCount > 1 && id % a.shardCount != a.shardRank) continue;
+            fs.hSuper.push_back(id);
+        }
+    if (fs.hSuper.empty()) return hipSuccess;
+    hipError_t e = fs.superTiles.put(fs.hSuper, stream);
+    if (e != hipSuccess) return e;
+
+    static int numCU = 0;
+    if (!numCU) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+        numCU = prop.multiProcessorCount;
+    }
+    FastLaunchConfig cfg = fastLaunchConfig();
+    chooseThresholds(cfg, fs);
+
+    FastScene sc;
+    sc.nodes = fs.nodes.p; sc.inst = fs.inst.p; sc.shade = fs.shade.p;
+    sc.tris = fs.tris.p; sc.nrms = fs.nrms.p; sc.triOrig = fs.triOrig.p; sc.superTiles = fs.superTiles.p; sc.nSuperTiles = (int)fs.hSuper.size();
+    sc.tlasRoot = fs.tlasRoot;
+    if ((e = fs.stackSpill.ensure((size_t)kSpillMax * (size_t)(numCU * cfg.blocksPerCU) * kBlockThreads)) != hipSuccess) return e;
+    sc.stackSpill = fs.stackSpill.p;
+    sc.blasBase = fs.tlasReserve;
+    auto hotRanges = [&](int budget, int32_t& hotTlas, int32_t& hotBlas) {
+        const int nb = fs.nBlasNodes < (size_t)budget ? (int)fs.nBlasNodes : budget;
+        int tl = budget - nb > budget / 2 ? budget - nb : budget / 2;
+        if (tl > fs.nTlasNodes) tl = fs.nTlasNodes;
+        hotTlas = tl;
+        hotBlas = budget - tl < nb ? budget - tl : nb;
+    };
+    hotRanges(kHotNodes, sc.hotTlas, sc.hotBlas);
+
+    if (a.outIds || a.outT) {
+        RenderArgs ids = a;
+        ids.outRgba = nullptr; ids.accum = nullptr; ids.spp = 1;
+        long long blocksNeeded = ((long long)fs.hSuper.size() * 1024 + kBlockThreads - 1) / kBlockThreads;
+        int grid = numCU * cfg.blocksPerCU;
+        if (blocksNeeded < grid) grid = (int)blocksNeeded;
+        hipLaunchKernelGGL((kFast<kModePrimary, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, ids, cfg.refillBelow, cfg.nodeMin,
+                           cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(a.rayCount, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+    }
+
+    // chunks of super-tiles x batches of samples, each at most `cap` paths in the sample buffer
+    const size_t cap = poolMaxPaths();
+    size_t tilesPerChunk = cap / 1024;
+    if (tilesPerChunk < 1) tilesPerChunk = 1;
+    if (tilesPerChunk > fs.hSuper.size()) tilesPerChunk = fs.hSuper.size();
+    const size_t workPerChunk = tilesPerChunk * 1024;
+    size_t samplesPerBatch = cap / workPerChunk;
+    if (samplesPerBatch < 1) samplesPerBatch = 1;
+    if (samplesPerBatch > (size_t)a.spp) samplesPerBatch = (size_t)a.spp;
+    const int gridMax = numCU * cfg.blocksPerCU;
+    int poolSlots = kPoolSlots;
+    if (const char* sv = getenv("RTAMD_POOL_SLOTS")) { int v = atoi(sv); if (v >= 64 && v <= kPoolSlots) poolSlots = v; }
+    if ((e = ph.recs.ensure((size_t)gridMax * (kBlockThreads / 64) * kPoolSlots)) != hipSuccess) return e;
+    if ((e = ph.sampleL.ensure(workPerChunk * samplesPerBatch)) != hipSuccess) return e;
+    if ((e = ph.runSum.ensure(workPerChunk)) != hipSuccess) return e;
+
+    for (size_t t0 = 0; t0 < fs.hSuper.size(); t0 += tilesPerChunk) {
+        const size_t nt = fs.hSuper.size() - t0 < tilesPerChunk ? fs.hSuper.size() - t0 : tilesPerChunk;
+        for (int s0 = 0; s0 < a.spp; s0 += (int)samplesPerBatch) {
+            PoolBatch b;
+            b.recs = ph.recs.p; b.sampleL = ph.sampleL.p; b.runSum = ph.runSum.p;
+            b.next = a.rayCount + 1;
+            b.nWork = (uint32_t)(nt * 1024); b.superBase = (int32_t)t0;
+            b.sampleBase = s0;
+            b.nSamples = a.spp - s0 < (int)samplesPerBatch ? a.spp - s0 : (int)samplesPerBatch;
+            b.firstBatch = s0 == 0; b.lastBatch = s0 + b.nSamples >= a.spp;
+            hotRanges(kPoolHotNodes, b.hotTlas, b.hotBlas);
+            const unsigned long long total = (unsigned long long)b.nWork * (unsigned long long)b.nSamples;
+            if ((e = hipMemsetAsync(a.rayCount + 1, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
+            long long blocksNeeded = (long long)((total + kBlockThreads - 1) / kBlockThreads);
+            int grid = blocksNeeded < gridMax ? (int)blocksNeeded : gridMax;
+            hipLaunchKernelGGL(kPool, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots);
+            hipLaunchKernelGGL(kPoolSum, dim3((b.nWork + 255) / 256), dim3(256), 0, stream, sc, a, b);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
+}  // namespace rt

@@ -17,6 +17,7 @@
 
 #include "kernel_faithful.h"
 #include "kernel_fast.h"
+#include "kernel_pool.h"
 #include "rtamd.h"
 
 static_assert(sizeof(rtamd_node) == 116, "Node stride");
@@ -72,6 +73,7 @@ struct rtamd_ctx {
 
     // GPU layout (production kernel)
     rt::FastSceneHost fast;
+    rt::PoolHost pool;                    // path records and sample buffer of kPool
 
     DevBuf<float4> sky;
     int skyW = 0, skyH = 0;
@@ -191,6 +193,7 @@ int rtamd_ctx_destroy(rtamd_ctx* c) {
     c->outRgba.release(); c->outIds.release(); c->outT.release(); c->counters.release(); c->rayCount.release();
     c->errorFlag.release(); c->redoMask.release(); c->redoList.release(); c->redoCount.release(); c->redoSamples.release();
     c->fast.release();
+    c->pool.release();
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
@@ -410,8 +413,10 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
             dim3 grid((width + 7) / 8, (height + 7) / 8);
             hipLaunchKernelGGL(rt::kFaithful, grid, dim3(64), 0, c->stream, rsc, sky, a, (const int32_t*)nullptr, 0, (float4*)nullptr);
         } else {
-            hipError_t le = rt::launchFast(c->fast, sky, a, c->stream);
-            if (le != hipSuccess) return failHip(c, le, "fast kernel launch");
+            hipError_t le = (a.mode == RTAMD_MODE_PT && rt::fastLaunchConfig().pool)
+                                ? rt::launchPool(c->fast, c->pool, sky, a, c->stream)
+                                : rt::launchFast(c->fast, sky, a, c->stream);
+            if (le != hipSuccess) return failHip(c, le, "production kernel launch");
         }
         HIP_TRY(c, hipGetLastError());
     }
