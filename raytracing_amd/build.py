@@ -36,13 +36,14 @@ def _run(cmd):
 
 def build_device(force=False):
     src = os.path.join(CSRC, "rtamd.hip")
-    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
+    tlas_src = os.path.join(CSRC, "tlas_build.hip")
+    deps = [src, tlas_src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     deps += [os.path.join(INC, "rtamd.h")]
     out = os.path.join(LIB, "librtamd.so")
     if force or _newer(out, deps):
         os.makedirs(LIB, exist_ok=True)
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc] + HIP_FLAGS + ["-I" + INC, "-I" + CSRC, src, "-o", out])
+        _run([hipcc] + HIP_FLAGS + ["-I" + INC, "-I" + CSRC, src, tlas_src, "-o", out])
     return out
 
 

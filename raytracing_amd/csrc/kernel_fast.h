@@ -45,59 +45,11 @@
 #include <vector>
 
 #include "kernel_common.h"
+#include "fast_layout.h"
+#include "tlas_build.h"
 #include "wide_bvh.h"
 
 namespace rt {
-
-struct alignas(128) WNode {
-    float4 lx, hx, ly, hy, lz, hz;
-    int4 child;
-    int4 pad;
-};
-struct alignas(64) FTri { float4 a, b, c, d; };
-struct alignas(16) FNrm { float4 a, b, c; };                            // n0.xyz n1.x | n1.yz n2.xy | n2.z
-struct alignas(32) FInst { float4 r0, r1, r2; float4 b0; float bhy, bhz; int32_t root, object; float4 pad; };   // b0 = lo.xyz, hi.x
-struct alignas(32) FShade { float4 r0, r1, r2; float4 albedo, specular, emission; };
-
-// child / stack words: >= 0 node index; < 0: ~payload, payload bit 30 set = instance rank,
-// clear = (first triangle << 2 | count-1).  kEmptyChild never reaches the stack.
-constexpr int32_t kEmptyChild = (int32_t)0x80000001;
-constexpr uint32_t kInstanceBit = 0x40000000u;
-
-struct FastScene {
-    const WNode* nodes;
-    const FInst* inst;
-    const FShade* shade;
-    const FTri* tris;
-    const FNrm* nrms;            // by triangle rank
-    const int32_t* triOrig;      // by triangle rank: the caller's triangle index
-    const int32_t* superTiles;   // ids of the 32x32 pixel tiles this launch owns
-    int32_t nSuperTiles;
-    int32_t tlasRoot;            // index of the TLAS root in nodes
-    // nodes kept in LDS by every workgroup: [0, hotTlas) and [blasBase, blasBase + hotBlas)
-    int32_t hotTlas, blasBase, hotBlas;
-    int32_t* stackSpill;         // overflow of the LDS traversal stacks: [kSpillMax][threads of the grid]
-};
-
-template <typename T>
-struct DBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    hipError_t ensure(size_t count) {
-        if (p && count <= n) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr; n = 0;
-        hipError_t e = hipMalloc((void**)&p, (count ? count : 1) * sizeof(T));
-        if (e == hipSuccess) n = count;
-        return e;
-    }
-    hipError_t put(const std::vector<T>& v, hipStream_t s) {
-        hipError_t e = ensure(v.size());
-        if (e != hipSuccess || v.empty()) return e;
-        return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-};
 
 // Host-side owner of the GPU layout.
 struct FastSceneHost {
@@ -123,9 +75,16 @@ struct FastSceneHost {
     int tlasRoot = 0;
     int maxDepth = 0;
 
+    // who builds the tree over the instances: 0 = by instance count, 1 = host (binned SAH), 2 = device (Morton order)
+    int tlasBuildMode = 0;
+    bool tlasBuiltOnDevice = false;
+    TlasDeviceBuilder* tlasBuilder = nullptr;
+
     void release() {
         nodes.release(); inst.release(); shade.release(); tris.release(); nrms.release(); triOrig.release();
         superTiles.release(); stackSpill.release(); stats.release();
+        tlasDeviceDestroy(tlasBuilder);
+        tlasBuilder = nullptr;
     }
 
     // Convert the nodes of a built tree; node i of the tree gets index remap[i].
@@ -327,6 +286,23 @@ struct FastSceneHost {
         if (hInst.empty()) { err = "TLAS references no object"; return hipSuccess; }
         if (hInst.size() >= kInstanceBit) { err = "too many instances"; return hipSuccess; }
         nInst = (int)hInst.size();
+        tlasRoot = 0;
+        hipError_t e;
+        int mode = tlasBuildMode;
+        if (const char* s = getenv("RTAMD_TLAS_BUILD")) mode = !strcmp(s, "device") ? 2 : (!strcmp(s, "host") ? 1 : mode);
+        // the device build needs room for nInst - 1 nodes whatever the tree turns out to be
+        const bool onDevice = (mode == 2 || (mode == 0 && nInst >= kTlasDeviceMin)) && tlasReserve >= (nInst > 2 ? nInst - 1 : 1);
+        tlasBuiltOnDevice = onDevice;
+        if (onDevice) {
+            if (!tlasBuilder && !(tlasBuilder = tlasDeviceCreate())) return hipErrorOutOfMemory;
+            if (!blasUploaded) {
+                if ((e = nodes.put(hNodes, stream)) != hipSuccess) return e;
+                blasUploaded = true;
+            }
+            if ((e = inst.put(hInst, stream)) != hipSuccess) return e;
+            if ((e = shade.put(hShade, stream)) != hipSuccess) return e;
+            return tlasDeviceBuild(tlasBuilder, inst.p, nInst, nodes.p, tlasReserve, stream, &nTlasNodes, &tlasDepth);
+        }
         WideTree tree;
         buildWideTree(boxes.data(), nInst, 1, tree);
         if ((int)tree.nodes.size() > tlasReserve) { err = "TLAS grew beyond the node range reserved at scene upload"; return hipSuccess; }
@@ -339,10 +315,8 @@ struct FastSceneHost {
                 return ~(int32_t)((uint32_t)tree.order[start] | kInstanceBit);
             });
         }
-        tlasRoot = 0;
         nTlasNodes = (int)tree.nodes.size();
         tlasDepth = tree.depth;
-        hipError_t e;
         if (!blasUploaded) {
             if ((e = nodes.put(hNodes, stream)) != hipSuccess) return e;
             blasUploaded = true;
@@ -350,6 +324,7 @@ struct FastSceneHost {
         if ((e = inst.put(hInst, stream)) != hipSuccess) return e;
         return shade.put(hShade, stream);
     }
+    static constexpr int kTlasDeviceMin = 4096;   // instances from which the device build is used when the caller does not choose
     int tlasDepth = 0;
     bool blasUploaded = false;
 };

@@ -204,6 +204,22 @@ int rtamd_set_stream(rtamd_ctx* c, void* s) {
     return RTAMD_OK;
 }
 
+int rtamd_set_tlas_build(rtamd_ctx* c, int32_t mode) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (mode < RTAMD_TLAS_BUILD_AUTO || mode > RTAMD_TLAS_BUILD_DEVICE) return fail(c, RTAMD_ERR_INVALID_ARG, "unknown TLAS build mode");
+    c->fast.tlasBuildMode = mode;
+    return RTAMD_OK;
+}
+
+int rtamd_tlas_info(const rtamd_ctx* c, int32_t* nodes, int32_t* levels, int32_t* built_on_device) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->haveScene) return RTAMD_ERR_NO_SCENE;
+    if (nodes) *nodes = c->fast.nTlasNodes;
+    if (levels) *levels = c->fast.tlasDepth;
+    if (built_on_device) *built_on_device = c->fast.tlasBuiltOnDevice ? 1 : 0;
+    return RTAMD_OK;
+}
+
 static int uploadTlasAndObjects(rtamd_ctx* c, const rtamd_node* tlas, int nTlas, const rtamd_object_property* objects,
                                 int nObjects) {
     int rc = validateTree(c, tlas, nTlas, nObjects, "TLAS");
