@@ -232,7 +232,7 @@ static int uploadTlasAndObjects(rtamd_ctx* c, const rtamd_node* tlas, int nTlas,
     c->nTlas = nTlas;
     c->nObjects = nObjects;
     std::string err;
-    hipError_t e = c->fast.buildTop(tlas, nTlas, objects, nObjects, c->stream, err);
+    hipError_t e = c->fast.buildTop(tlas, nTlas, objects, nObjects, c->tlas.p, c->objects.p, c->stream, err);
     if (e != hipSuccess) return failHip(c, e, "TLAS re-pack");
     if (!err.empty()) return fail(c, RTAMD_ERR_BAD_INDEX, err);
     HIP_TRY(c, hipStreamSynchronize(c->stream));

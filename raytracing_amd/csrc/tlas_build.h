@@ -11,6 +11,7 @@
 #pragma once
 
 #include "fast_layout.h"
+#include "rtamd.h"
 
 namespace rt {
 
@@ -24,5 +25,11 @@ void tlasDeviceDestroy(TlasDeviceBuilder* b);
 // On return the stream has been synchronised and *nNodes / *depth describe the tree.
 hipError_t tlasDeviceBuild(TlasDeviceBuilder* b, const FInst* inst, int n, WNode* nodesOut, int reserve,
                            hipStream_t stream, int* nNodes, int* depth);
+
+// Fills inst[r] / shade[r] for r in [0, n) from the caller's TLAS and object array as they lie in
+// device memory: instance r is the one in leaf slot (slotOf[r] & 3) of TLAS node (slotOf[r] >> 2);
+// blasRoot maps a BLAS index to the root of its tree in the production kernel's node array.
+hipError_t tlasPackInstances(const rtamd_node* tlas, const rtamd_object_property* objects, const int32_t* slotOf,
+                             const int32_t* blasRoot, int n, FInst* inst, FShade* shade, hipStream_t stream);
 
 }  // namespace rt

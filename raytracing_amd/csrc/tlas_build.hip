@@ -105,9 +105,9 @@ __device__ __forceinline__ uint64_t spread21(uint64_t x) {
     x = (x | x << 2) & 0x1249249249249249ull;
     return x;
 }
-__device__ __forceinline__ uint32_t quantise(float c, float lo, float hi) {
-    if (!(hi > lo)) return 0u;
-    const float q = (c - lo) * (2097152.0f / (hi - lo));
+// all three axes share one scale (the largest extent), so that a flat scene is not cut along its thin axis
+__device__ __forceinline__ uint32_t quantise(float c, float lo, float scale) {
+    const float q = (c - lo) * scale;
     if (!(q > 0.f)) return 0u;
     return q >= 2097151.0f ? 2097151u : (uint32_t)q;
 }
@@ -117,9 +117,12 @@ __global__ __launch_bounds__(kThreads) void kTlasMorton(const FInst* inst, int n
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
     const Box3 b = instBox(inst, (uint32_t)i);
-    const uint32_t qx = quantise(centre(b.lx, b.hx), fromOrderedBits(bounds[0]), fromOrderedBits(bounds[3]));
-    const uint32_t qy = quantise(centre(b.ly, b.hy), fromOrderedBits(bounds[1]), fromOrderedBits(bounds[4]));
-    const uint32_t qz = quantise(centre(b.lz, b.hz), fromOrderedBits(bounds[2]), fromOrderedBits(bounds[5]));
+    const float lx = fromOrderedBits(bounds[0]), ly = fromOrderedBits(bounds[1]), lz = fromOrderedBits(bounds[2]);
+    const float extent = fmaxf(fmaxf(fromOrderedBits(bounds[3]) - lx, fromOrderedBits(bounds[4]) - ly), fromOrderedBits(bounds[5]) - lz);
+    const float scale = extent > 0.f ? 2097152.0f / extent : 0.f;
+    const uint32_t qx = quantise(centre(b.lx, b.hx), lx, scale);
+    const uint32_t qy = quantise(centre(b.ly, b.hy), ly, scale);
+    const uint32_t qz = quantise(centre(b.lz, b.hz), lz, scale);
     keys[i] = (spread21(qx) << 2) | (spread21(qy) << 1) | spread21(qz);
     vals[i] = (uint32_t)i;
 }
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(kThreads) void kTlasRefit(const FInst* inst, const 
     }
 }
 
+
 __device__ __forceinline__ Box3 childBox(const FInst* inst, const uint32_t* vals, const float4* blo, const float4* bhi, int32_t c) {
     if (c >= 0) {
         const float4 lo = blo[c], hi = bhi[c];
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(kCollapseThreads) void kTlasCollapse(const FInst* i
     }
     int32_t* cur = queueA;
     int32_t* nxt = queueB;
-    if (tid == 0) cur[0] = 0;
+    if (tid == 0) cur[0] = 0;      // the root of the radix tree
     __syncthreads();
     int levelBase = 0, levelCount = 1, depth = 0;
     while (levelCount > 0) {
@@ -316,6 +320,38 @@ __global__ __launch_bounds__(kCollapseThreads) void kTlasCollapse(const FInst* i
     if (tid == 0) { result[0] = levelBase; result[1] = depth; }
 }
 
+// Per-instance records of the production kernel from the caller's arrays as uploaded: instance r
+// sits in leaf slot (slotOf[r] & 3) of TLAS node (slotOf[r] >> 2).
+__global__ __launch_bounds__(kThreads) void kTlasPack(const rtamd_node* tlas, const rtamd_object_property* objects, const int32_t* slotOf,
+                                                      const int32_t* blasRoot, int n, FInst* inst, FShade* shade) {
+    const int r = blockIdx.x * kThreads + threadIdx.x;
+    if (r >= n) return;
+    const int32_t code = slotOf[r];
+    const rtamd_node& nd = tlas[code >> 2];
+    const int i = code & 3;
+    const int32_t d = nd.Data[i];
+    const rtamd_object_property& o = objects[d];
+    FInst fi;
+    const float* m = o.WorldToLocal;
+    fi.r0 = make_float4(m[0], m[4], m[8], m[12]);
+    fi.r1 = make_float4(m[1], m[5], m[9], m[13]);
+    fi.r2 = make_float4(m[2], m[6], m[10], m[14]);
+    fi.b0 = make_float4(nd.Lx[i], nd.Ly[i], nd.Lz[i], nd.Hx[i]);
+    fi.bhy = nd.Hy[i]; fi.bhz = nd.Hz[i];
+    fi.root = blasRoot[o.BLASIndex]; fi.object = d;
+    fi.pad = make_float4(0.f, 0.f, 0.f, 0.f);
+    inst[r] = fi;
+    FShade fs;
+    const float* l = o.LocalToWorld;
+    fs.r0 = make_float4(l[0], l[4], l[8], l[12]);
+    fs.r1 = make_float4(l[1], l[5], l[9], l[13]);
+    fs.r2 = make_float4(l[2], l[6], l[10], l[14]);
+    fs.albedo = make_float4(o.albedo[0], o.albedo[1], o.albedo[2], o.albedo[3]);
+    fs.specular = make_float4(o.specular[0], o.specular[1], o.specular[2], o.specular[3]);
+    fs.emission = make_float4(o.emission[0], o.emission[1], o.emission[2], o.emission[3]);
+    shade[r] = fs;
+}
+
 template <typename T>
 struct Buf {
     T* p = nullptr;
@@ -351,6 +387,14 @@ void tlasDeviceDestroy(TlasDeviceBuilder* b) {
     delete b;
 }
 
+hipError_t tlasPackInstances(const rtamd_node* tlas, const rtamd_object_property* objects, const int32_t* slotOf,
+                             const int32_t* blasRoot, int n, FInst* inst, FShade* shade, hipStream_t stream) {
+    if (!tlas || !objects || !slotOf || !blasRoot || !inst || !shade || n < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kTlasPack, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, tlas, objects, slotOf,
+                       blasRoot, n, inst, shade);
+    return hipGetLastError();
+}
+
 hipError_t tlasDeviceBuild(TlasDeviceBuilder* b, const FInst* inst, int n, WNode* nodesOut, int reserve, hipStream_t stream,
                            int* nNodes, int* depth) {
     if (!b || !inst || !nodesOut || n < 1 || reserve < (n > 2 ? n - 1 : 1)) return hipErrorInvalidValue;
@@ -360,7 +404,7 @@ hipError_t tlasDeviceBuild(TlasDeviceBuilder* b, const FInst* inst, int n, WNode
         (e = b->valsB.ensure(N)) != hipSuccess || (e = b->bounds.ensure(8)) != hipSuccess || (e = b->left.ensure(N)) != hipSuccess ||
         (e = b->right.ensure(N)) != hipSuccess || (e = b->parentInner.ensure(N)) != hipSuccess || (e = b->parentLeaf.ensure(N)) != hipSuccess ||
         (e = b->flags.ensure(N)) != hipSuccess || (e = b->queueA.ensure(N)) != hipSuccess || (e = b->queueB.ensure(N)) != hipSuccess ||
-        (e = b->result.ensure(2)) != hipSuccess || (e = b->blo.ensure(N)) != hipSuccess || (e = b->bhi.ensure(N)) != hipSuccess)
+        (e = b->result.ensure(4)) != hipSuccess || (e = b->blo.ensure(N)) != hipSuccess || (e = b->bhi.ensure(N)) != hipSuccess)
         return e;
     const unsigned grid = (unsigned)((N + kThreads - 1) / kThreads);
     hipLaunchKernelGGL(kTlasInit, dim3(1), dim3(64), 0, stream, b->bounds.p, b->parentInner.p, b->result.p);

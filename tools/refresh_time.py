@@ -7,10 +7,13 @@ import time
 sys.path.insert(0, ".")
 from raytracing_amd import backend, scenes, types as T
 
-counts = [int(a) for a in sys.argv[1:]] or [484, 1250, 5000, 20000, 100000]
+scattered = "--scattered" in sys.argv
+counts = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [484, 1250, 5000, 20000, 100000]
 w, h = 1920, 1080
 for n in counts:
-    if n == 484:
+    if scattered:
+        buf, frame, sky = scenes.scattered_scene(w, h, instances=n)
+    elif n == 484:
         buf, frame, sky = scenes.random_spheres(w, h)
     else:
         buf, frame, sky = scenes.instanced_scene(w, h, instances=n, tris_per_blas=2000, tlas_tree=1)
