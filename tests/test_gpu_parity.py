@@ -261,3 +261,54 @@ def test_tlas_built_on_the_device_single_object(device_tlas, oracle):
     o = oracle.render(buf, frame, w, h, sky=sky, mode=1, spp=2, max_bounces=3, seed=2)
     assert _same(g["ids"], o["ids"]) and _same(g["rgba"], o["rgba"])
     assert (o["ids"][..., 0] >= 0).any()
+
+
+def test_4k_frame_production_kernel_equals_reference_order_kernel(gpu_pass):
+    """3840x2160 (the multi-GPU configuration's frame): production and reference-order kernels agree
+    on every pixel, and four interleaved tile shards compose to the whole frame."""
+    from raytracing_amd import scenes
+    w, h = 3840, 2160
+    buf, frame, sky = scenes.mesh_scene(w, h, target_tris=200_000)
+    gpu_pass.SetScene(buf)
+    gpu_pass.SetSkyBox(sky)
+    kw = dict(mode=T.MODE_PT, spp=1, max_bounces=8, seed=4)
+    fast = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, **kw)
+    ref = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, flags=T.FLAG_REFERENCE_ORDER, **kw)
+    assert _same(fast["ids"], ref["ids"]), _report("4k", fast, ref)
+    assert _same(fast["t"], ref["t"])
+    assert _same(fast["rgba"], ref["rgba"]), _report("4k", fast, ref)
+    assert fast["rays"] == ref["rays"]
+    assert (fast["ids"][..., 0] >= 0).mean() > 0.2
+    parts = np.zeros_like(fast["rgba"])
+    rays = 0
+    for r in range(4):
+        part = np.zeros_like(parts)
+        rays += gpu_pass.Execute(frame, w, h, out_rgba=part, shard_rank=r, shard_count=4, **kw)["rays"]
+        parts += part
+    assert _same(parts, fast["rgba"])
+    assert rays == fast["rays"]
+
+
+def test_fifty_million_instanced_triangles(gpu_pass):
+    """1 250 instances of 40 000-triangle meshes (the largest configuration's scene): production
+    kernel, on a host-built and on a device-built top-level tree, against the reference-order kernel."""
+    from raytracing_amd import scenes
+    w, h = 640, 360
+    buf, frame, sky = scenes.instanced_scene(w, h, instances=1250, tris_per_blas=40_000)
+    tri_count = np.array([buf.blas_slice(b)[1] for b in range(buf.n_blas)])
+    assert int(tri_count[buf.objects["BLASIndex"]].sum()) > 49_000_000
+    gpu_pass.SetSkyBox(sky)
+    kw = dict(mode=T.MODE_PT, spp=2, max_bounces=6, seed=12)
+    results = []
+    for build in ("host", "device"):
+        gpu_pass.SetTlasBuild(build)
+        gpu_pass.SetScene(buf)
+        results.append(gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, **kw))
+    gpu_pass.SetTlasBuild("auto")
+    ref = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, flags=T.FLAG_REFERENCE_ORDER, **kw)
+    for g in results:
+        assert _same(g["ids"], ref["ids"]), _report("50M", g, ref)
+        assert _same(g["t"], ref["t"])
+        assert _same(g["rgba"], ref["rgba"]), _report("50M", g, ref)
+        assert g["rays"] == ref["rays"]
+    assert (ref["ids"][..., 0] > 0).mean() > 0.2
