@@ -170,6 +170,24 @@ int rtamd_scene_refresh_objects(rtamd_ctx* ctx,
                                 const rtamd_node* tlas, int32_t n_tlas_nodes,
                                 const rtamd_object_property* objects, int32_t n_objects);
 
+/* Who builds the library's own tree over the instances on a scene upload or an object
+ * refresh.  The reference rebuilds its TLAS on the CPU every frame
+ * (BuildAccelerateStructureSystem.cs:56-66, TopLevelAccelerateStructure.cs:14-40); that
+ * tree is still taken from the caller and decides ties, but the production kernel walks a
+ * private tree over the same instance boxes, rebuilt either on the host (binned SAH: best
+ * tree, about a microsecond per instance) or on the GPU (Morton order + binary radix tree,
+ * collapsed to 4-wide nodes: constant time up to ~10^5 instances).  AUTO picks the GPU
+ * from 4096 instances on.  Which instance a ray hits does not depend on the choice. */
+#define RTAMD_TLAS_BUILD_AUTO 0
+#define RTAMD_TLAS_BUILD_HOST 1
+#define RTAMD_TLAS_BUILD_DEVICE 2
+int rtamd_set_tlas_build(rtamd_ctx* ctx, int32_t mode);
+
+/* Shape of that private tree after the last upload / refresh: number of 4-wide nodes,
+ * number of levels, and whether it was built on the GPU (1) or the host (0).  Any
+ * pointer may be NULL. */
+int rtamd_tlas_info(const rtamd_ctx* ctx, int32_t* nodes, int32_t* levels, int32_t* built_on_device);
+
 /* Replaces SetComputeTextureParam(.., "_SkyboxTexture", ..) (RayTracingPass.cs:85).
  * rgba32f: height rows of width RGBA float texels, row 0 = v 0.  Sampled
  * bilinear, repeat, mip 0 (Assets/SkyBoxes/dikhololo_night_4k.exr.meta:33,36,39-40).

@@ -16,7 +16,7 @@ _lib = None
 
 EXPORTS = ["rtamd_ctx_create", "rtamd_ctx_destroy", "rtamd_last_error_string", "rtamd_scene_upload",
            "rtamd_scene_refresh_objects", "rtamd_sky_upload", "rtamd_render", "rtamd_accum_reset",
-           "rtamd_set_stream", "rtamd_last_render_stats", "rtamd_last_handover_stats", "rtamd_composite_add", "rtamd_present", "rtamd_version"]
+           "rtamd_set_stream", "rtamd_set_tlas_build", "rtamd_tlas_info", "rtamd_last_render_stats", "rtamd_last_handover_stats", "rtamd_composite_add", "rtamd_present", "rtamd_version"]
 
 
 class BackendError(RuntimeError):
@@ -45,6 +45,8 @@ def lib():
         L.rtamd_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(T.ExtParams), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.rtamd_accum_reset.argtypes = [C.c_void_p]
         L.rtamd_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.rtamd_set_tlas_build.argtypes = [C.c_void_p, C.c_int32]
+        L.rtamd_tlas_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.rtamd_last_render_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
         L.rtamd_last_handover_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.rtamd_composite_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
@@ -126,6 +128,16 @@ class RayTracingPass:
 
     def SetStream(self, stream_ptr):
         self._check(lib().rtamd_set_stream(self._ctx, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def SetTlasBuild(self, mode):
+        """'auto' | 'host' | 'device': who rebuilds the library's private tree over the instances
+        (the reference's per-frame TLAS build, BuildAccelerateStructureSystem.cs:56-66)."""
+        self._check(lib().rtamd_set_tlas_build(self._ctx, {"auto": 0, "host": 1, "device": 2}[mode]))
+
+    def TlasInfo(self):
+        n, lv, dev = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._check(lib().rtamd_tlas_info(self._ctx, C.byref(n), C.byref(lv), C.byref(dev)))
+        return {"nodes": n.value, "levels": lv.value, "built_on_device": bool(dev.value)}
 
     def ResetAccumulation(self):
         self._check(lib().rtamd_accum_reset(self._ctx))

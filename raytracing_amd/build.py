@@ -17,7 +17,7 @@ INC = os.path.join(ROOT, "include")
 
 # -ffp-contract=off: the kernels and the oracle must round every product and sum
 # separately so that both give the same bits.
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 CXX_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-pthread",
              "-Wall", "-Wno-misleading-indentation"]
 
@@ -36,13 +36,15 @@ def _run(cmd):
 
 def build_device(force=False):
     src = os.path.join(CSRC, "rtamd.hip")
-    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
+    tlas_src = os.path.join(CSRC, "tlas_build.hip")
+    deps = [src, tlas_src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     deps += [os.path.join(INC, "rtamd.h")]
     out = os.path.join(LIB, "librtamd.so")
     if force or _newer(out, deps):
         os.makedirs(LIB, exist_ok=True)
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc] + HIP_FLAGS + ["-I" + INC, "-I" + CSRC, src, "-o", out])
+        extra = os.environ.get("RTAMD_EXTRA_HIPFLAGS", "").split()      # experiments only
+        _run([hipcc] + HIP_FLAGS + extra + ["-I" + INC, "-I" + CSRC, src, tlas_src, "-o", out])
     return out
 
 

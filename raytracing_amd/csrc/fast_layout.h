@@ -1,0 +1,62 @@
+// GPU-side scene layout of the production path: record types shared by the traversal kernel
+// and the device-side tree builder (see kernel_fast.h for what each record holds).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+namespace rt {
+
+struct alignas(128) WNode {
+    float4 lx, hx, ly, hy, lz, hz;
+    int4 child;
+    int4 pad;
+};
+struct alignas(64) FTri { float4 a, b, c, d; };
+struct alignas(16) FNrm { float4 a, b, c; };                            // n0.xyz n1.x | n1.yz n2.xy | n2.z
+struct alignas(32) FInst { float4 r0, r1, r2; float4 b0; float bhy, bhz; int32_t root, object; float4 pad; };   // b0 = lo.xyz, hi.x
+struct alignas(32) FShade { float4 r0, r1, r2; float4 albedo, specular, emission; };
+
+// child / stack words: >= 0 node index; < 0: ~payload, payload bit 30 set = instance rank,
+// clear = (first triangle << 2 | count-1).  kEmptyChild never reaches the stack.
+constexpr int32_t kEmptyChild = (int32_t)0x80000001;
+constexpr uint32_t kInstanceBit = 0x40000000u;
+
+struct FastScene {
+    const WNode* nodes;
+    const FInst* inst;
+    const FShade* shade;
+    const FTri* tris;
+    const FNrm* nrms;            // by triangle rank
+    const int32_t* triOrig;      // by triangle rank: the caller's triangle index
+    const int32_t* superTiles;   // ids of the 32x32 pixel tiles this launch owns
+    int32_t nSuperTiles;
+    int32_t tlasRoot;            // index of the TLAS root in nodes
+    // nodes kept in LDS by every workgroup: [0, hotTlas) and [blasBase, blasBase + hotBlas)
+    int32_t hotTlas, blasBase, hotBlas;
+    int32_t* stackSpill;         // overflow of the LDS traversal stacks: [kSpillMax][threads of the grid]
+};
+
+template <typename T>
+struct DBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t count) {
+        if (p && count <= n) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc((void**)&p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t put(const std::vector<T>& v, hipStream_t s) {
+        hipError_t e = ensure(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+}  // namespace rt

@@ -183,8 +183,11 @@ __device__ __forceinline__ uint32_t waveMax(uint32_t v) {
 // one-dimensional: in REF mode thread i renders pixel list[i]; in PT mode thread i traces
 // ONE sample, i % spp, of pixel list[i / spp] into sampleOut[i], and kSumListedSamples adds
 // a pixel's samples in sample order afterwards (the same order a single thread would use).
+// A short list is spread out: only every (1 << listSpread)-th lane takes an item, so that the few
+// paths there are do not wait for each other's branches inside a wave (the nested TLAS / BLAS loops
+// of the reference order serialise lanes that are in different instances).
 __global__ __launch_bounds__(64) void kFaithful(RefScene sc, Sky sky, RenderArgs a, const int32_t* list, int listCount,
-                                                float4* sampleOut) {
+                                                float4* sampleOut, int listSpread) {
     int x = blockIdx.x * 8 + (threadIdx.x & 7);
     int y = blockIdx.y * 8 + (threadIdx.x >> 3);
     bool inside;
@@ -192,9 +195,10 @@ __global__ __launch_bounds__(64) void kFaithful(RefScene sc, Sky sky, RenderArgs
     bool doPrimary = true;
     int gi = 0;
     if (list) {
-        gi = blockIdx.x * 64 + threadIdx.x;
+        const unsigned slot = blockIdx.x * 64u + threadIdx.x;
+        gi = (int)(slot >> listSpread);
         const int per = a.mode == RTAMD_MODE_PT ? a.spp : 1;
-        inside = gi < listCount * per;
+        inside = (slot & ((1u << listSpread) - 1u)) == 0u && (long long)gi < (long long)listCount * per;
         int p = inside ? list[gi / per] : 0;
         x = p % a.width;
         y = p / a.width;

@@ -45,59 +45,11 @@
 #include <vector>
 
 #include "kernel_common.h"
+#include "fast_layout.h"
+#include "tlas_build.h"
 #include "wide_bvh.h"
 
 namespace rt {
-
-struct alignas(128) WNode {
-    float4 lx, hx, ly, hy, lz, hz;
-    int4 child;
-    int4 pad;
-};
-struct alignas(64) FTri { float4 a, b, c, d; };
-struct alignas(16) FNrm { float4 a, b, c; };                            // n0.xyz n1.x | n1.yz n2.xy | n2.z
-struct alignas(32) FInst { float4 r0, r1, r2; float4 b0; float bhy, bhz; int32_t root, object; float4 pad; };   // b0 = lo.xyz, hi.x
-struct alignas(32) FShade { float4 r0, r1, r2; float4 albedo, specular, emission; };
-
-// child / stack words: >= 0 node index; < 0: ~payload, payload bit 30 set = instance rank,
-// clear = (first triangle << 2 | count-1).  kEmptyChild never reaches the stack.
-constexpr int32_t kEmptyChild = (int32_t)0x80000001;
-constexpr uint32_t kInstanceBit = 0x40000000u;
-
-struct FastScene {
-    const WNode* nodes;
-    const FInst* inst;
-    const FShade* shade;
-    const FTri* tris;
-    const FNrm* nrms;            // by triangle rank
-    const int32_t* triOrig;      // by triangle rank: the caller's triangle index
-    const int32_t* superTiles;   // ids of the 32x32 pixel tiles this launch owns
-    int32_t nSuperTiles;
-    int32_t tlasRoot;            // index of the TLAS root in nodes
-    // nodes kept in LDS by every workgroup: [0, hotTlas) and [blasBase, blasBase + hotBlas)
-    int32_t hotTlas, blasBase, hotBlas;
-    int32_t* stackSpill;         // overflow of the LDS traversal stacks: [kSpillMax][threads of the grid]
-};
-
-template <typename T>
-struct DBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    hipError_t ensure(size_t count) {
-        if (p && count <= n) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr; n = 0;
-        hipError_t e = hipMalloc((void**)&p, (count ? count : 1) * sizeof(T));
-        if (e == hipSuccess) n = count;
-        return e;
-    }
-    hipError_t put(const std::vector<T>& v, hipStream_t s) {
-        hipError_t e = ensure(v.size());
-        if (e != hipSuccess || v.empty()) return e;
-        return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-};
 
 // Host-side owner of the GPU layout.
 struct FastSceneHost {
@@ -116,16 +68,23 @@ struct FastSceneHost {
     std::vector<WNode> hNodes;
     size_t nBlasNodes = 0;
     int tlasReserve = 0, nTlasNodes = 0;
-    std::vector<FInst> hInst;
-    std::vector<FShade> hShade;
+    std::vector<int32_t> hSlotOf;      // per instance (visiting order): TLAS node << 2 | leaf slot
+    DBuf<int32_t> slotOf, dBlasRoot;
     std::vector<int32_t> hSuper;
     int nInst = 0;
     int tlasRoot = 0;
     int maxDepth = 0;
 
+    // who builds the tree over the instances: 0 = by instance count, 1 = host (binned SAH), 2 = device (Morton order)
+    int tlasBuildMode = 0;
+    bool tlasBuiltOnDevice = false;
+    TlasDeviceBuilder* tlasBuilder = nullptr;
+
     void release() {
         nodes.release(); inst.release(); shade.release(); tris.release(); nrms.release(); triOrig.release();
-        superTiles.release(); stackSpill.release(); stats.release();
+        superTiles.release(); stackSpill.release(); stats.release(); slotOf.release(); dBlasRoot.release();
+        tlasDeviceDestroy(tlasBuilder);
+        tlasBuilder = nullptr;
     }
 
     // Convert the nodes of a built tree; node i of the tree gets index remap[i].
@@ -285,10 +244,13 @@ struct FastSceneHost {
     // in the reference's visiting order (IntersectTLAS, .compute:355-381: inner children
     // popped last first, leaf slots 0..3) and keep the box of their TLAS leaf slot.
     hipError_t buildTop(const rtamd_node* tlas, int nTlas, const rtamd_object_property* objects, int nObjects,
-                        hipStream_t stream, std::string& err) {
-        (void)nObjects; (void)nTlas;
-        hInst.clear(); hShade.clear();
-        std::vector<BuildBox> boxes;
+                        const rtamd_node* dTlas, const rtamd_object_property* dObjects, hipStream_t stream, std::string& err) {
+        (void)nObjects; (void)nTlas; (void)objects;
+        int mode = tlasBuildMode;
+        if (const char* s = getenv("RTAMD_TLAS_BUILD")) mode = !strcmp(s, "device") ? 2 : (!strcmp(s, "host") ? 1 : mode);
+        // where each instance sits in the caller's tree, in visiting order; the per-instance records
+        // are then filled on the GPU from the caller's arrays as uploaded
+        hSlotOf.clear();
         std::vector<int32_t> st;
         st.push_back(1);
         while (!st.empty()) {
@@ -299,38 +261,27 @@ struct FastSceneHost {
                 for (int i = 0; i < 4; i++) if (n.Data[i] != 0) st.push_back(n.Data[i]);
                 continue;
             }
-            for (int i = 0; i < 4; i++) {
-                int d = n.Data[i];
-                if (d == -1) continue;
-                const rtamd_object_property& o = objects[d];
-                FInst fi;
-                const float* m = o.WorldToLocal;
-                fi.r0 = make_float4(m[0], m[4], m[8], m[12]);
-                fi.r1 = make_float4(m[1], m[5], m[9], m[13]);
-                fi.r2 = make_float4(m[2], m[6], m[10], m[14]);
-                fi.b0 = make_float4(n.Lx[i], n.Ly[i], n.Lz[i], n.Hx[i]); fi.bhy = n.Hy[i]; fi.bhz = n.Hz[i];
-                fi.root = blasRoot[o.BLASIndex]; fi.object = d; fi.pad = make_float4(0.f, 0.f, 0.f, 0.f);
-                hInst.push_back(fi);
-                FShade fs;
-                const float* l = o.LocalToWorld;
-                fs.r0 = make_float4(l[0], l[4], l[8], l[12]);
-                fs.r1 = make_float4(l[1], l[5], l[9], l[13]);
-                fs.r2 = make_float4(l[2], l[6], l[10], l[14]);
-                fs.albedo = make_float4(o.albedo[0], o.albedo[1], o.albedo[2], o.albedo[3]);
-                fs.specular = make_float4(o.specular[0], o.specular[1], o.specular[2], o.specular[3]);
-                fs.emission = make_float4(o.emission[0], o.emission[1], o.emission[2], o.emission[3]);
-                hShade.push_back(fs);
-                BuildBox bx = {{n.Lx[i], n.Ly[i], n.Lz[i]}, {n.Hx[i], n.Hy[i], n.Hz[i]}};
-                boxes.push_back(bx);
-            }
+            for (int i = 0; i < 4; i++)
+                if (n.Data[i] != -1) hSlotOf.push_back((int32_t)((uint32_t)ni << 2 | (uint32_t)i));
         }
-        if (hInst.empty()) { err = "TLAS references no object"; return hipSuccess; }
-        if (hInst.size() >= kInstanceBit) { err = "too many instances"; return hipSuccess; }
-        nInst = (int)hInst.size();
+        if (hSlotOf.empty()) { err = "TLAS references no object"; return hipSuccess; }
+        if (hSlotOf.size() >= kInstanceBit || (unsigned)nTlas >= (1u << 29)) { err = "too many instances"; return hipSuccess; }
+        nInst = (int)hSlotOf.size();
+        tlasRoot = 0;
+        hipError_t e;
+        // the device build needs room for nInst - 1 nodes whatever the tree turns out to be
+        const bool onDevice = (mode == 2 || (mode == 0 && nInst >= kTlasDeviceMin)) && tlasReserve >= (nInst > 2 ? nInst - 1 : 1);
+        tlasBuiltOnDevice = onDevice;
         WideTree tree;
-        buildWideTree(boxes.data(), nInst, 1, tree);
-        if ((int)tree.nodes.size() > tlasReserve) { err = "TLAS grew beyond the node range reserved at scene upload"; return hipSuccess; }
-        {
+        if (!onDevice) {
+            std::vector<BuildBox> boxes((size_t)nInst);
+            for (int r = 0; r < nInst; r++) {
+                const rtamd_node& n = tlas[hSlotOf[r] >> 2];
+                const int i = hSlotOf[r] & 3;
+                boxes[r] = {{n.Lx[i], n.Ly[i], n.Lz[i]}, {n.Hx[i], n.Hy[i], n.Hz[i]}};
+            }
+            buildWideTree(boxes.data(), nInst, 1, tree);
+            if ((int)tree.nodes.size() > tlasReserve) { err = "TLAS grew beyond the node range reserved at scene upload"; return hipSuccess; }
             std::vector<int32_t> order, levelStart, remap(tree.nodes.size());
             levelOrder(tree, order, levelStart);
             for (size_t i = 0; i < order.size(); i++) remap[order[i]] = (int32_t)i;
@@ -338,18 +289,24 @@ struct FastSceneHost {
                 (void)count;   // one instance per leaf: the leaf's box is the instance's own TLAS slot box
                 return ~(int32_t)((uint32_t)tree.order[start] | kInstanceBit);
             });
+            nTlasNodes = (int)tree.nodes.size();
+            tlasDepth = tree.depth;
         }
-        tlasRoot = 0;
-        nTlasNodes = (int)tree.nodes.size();
-        tlasDepth = tree.depth;
-        hipError_t e;
         if (!blasUploaded) {
             if ((e = nodes.put(hNodes, stream)) != hipSuccess) return e;
+            if ((e = dBlasRoot.put(blasRoot, stream)) != hipSuccess) return e;
             blasUploaded = true;
-        } else if ((e = hipMemcpyAsync(nodes.p, hNodes.data(), (size_t)nTlasNodes * sizeof(WNode), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-        if ((e = inst.put(hInst, stream)) != hipSuccess) return e;
-        return shade.put(hShade, stream);
+        } else if (!onDevice && (e = hipMemcpyAsync(nodes.p, hNodes.data(), (size_t)nTlasNodes * sizeof(WNode), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+        if ((e = slotOf.put(hSlotOf, stream)) != hipSuccess) return e;
+        if ((e = inst.ensure((size_t)nInst)) != hipSuccess || (e = shade.ensure((size_t)nInst)) != hipSuccess) return e;
+        if ((e = tlasPackInstances(dTlas, dObjects, slotOf.p, dBlasRoot.p, nInst, inst.p, shade.p, stream)) != hipSuccess) return e;
+        if (onDevice) {
+            if (!tlasBuilder && !(tlasBuilder = tlasDeviceCreate())) return hipErrorOutOfMemory;
+            return tlasDeviceBuild(tlasBuilder, inst.p, nInst, nodes.p, tlasReserve, stream, &nTlasNodes, &tlasDepth);
+        }
+        return hipSuccess;
     }
+    static constexpr int kTlasDeviceMin = 4096;   // instances from which the device build is used when the caller does not choose
     int tlasDepth = 0;
     bool blasUploaded = false;
 };

@@ -120,6 +120,16 @@ bool isDevicePointer(const void* p) {
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
 
+// Lanes left idle between the items of a hand-over list (log2): as many as keep the launch within
+// the number of waves the GPU holds at once, so a short list runs one path per wave.
+int listSpreadFor(size_t items) {
+    const size_t residentLanes = (size_t)256 * 32 * 64;      // 256 CUs x 8 waves per SIMD x 4 SIMDs, 64 lanes each
+    int spread = 0;
+    if (const char* s = getenv("RTAMD_LIST_SPREAD")) return atoi(s) < 0 ? 0 : (atoi(s) > 6 ? 6 : atoi(s));
+    while (spread < 6 && (items << (spread + 1)) <= residentLanes) spread++;
+    return spread;
+}
+
 // Walk the nodes reachable from node 1 of one tree and check every index the kernels
 // will follow.  leafLimit = number of primitives (objects for the TLAS).
 int validateTree(rtamd_ctx* c, const rtamd_node* nodes, int nNodes, int leafLimit, const char* what) {
@@ -207,6 +217,22 @@ int rtamd_set_stream(rtamd_ctx* c, void* s) {
     return RTAMD_OK;
 }
 
+int rtamd_set_tlas_build(rtamd_ctx* c, int32_t mode) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (mode < RTAMD_TLAS_BUILD_AUTO || mode > RTAMD_TLAS_BUILD_DEVICE) return fail(c, RTAMD_ERR_INVALID_ARG, "unknown TLAS build mode");
+    c->fast.tlasBuildMode = mode;
+    return RTAMD_OK;
+}
+
+int rtamd_tlas_info(const rtamd_ctx* c, int32_t* nodes, int32_t* levels, int32_t* built_on_device) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->haveScene) return RTAMD_ERR_NO_SCENE;
+    if (nodes) *nodes = c->fast.nTlasNodes;
+    if (levels) *levels = c->fast.tlasDepth;
+    if (built_on_device) *built_on_device = c->fast.tlasBuiltOnDevice ? 1 : 0;
+    return RTAMD_OK;
+}
+
 static int uploadTlasAndObjects(rtamd_ctx* c, const rtamd_node* tlas, int nTlas, const rtamd_object_property* objects,
                                 int nObjects) {
     int rc = validateTree(c, tlas, nTlas, nObjects, "TLAS");
@@ -219,7 +245,7 @@ static int uploadTlasAndObjects(rtamd_ctx* c, const rtamd_node* tlas, int nTlas,
     c->nTlas = nTlas;
     c->nObjects = nObjects;
     std::string err;
-    hipError_t e = c->fast.buildTop(tlas, nTlas, objects, nObjects, c->stream, err);
+    hipError_t e = c->fast.buildTop(tlas, nTlas, objects, nObjects, c->tlas.p, c->objects.p, c->stream, err);
     if (e != hipSuccess) return failHip(c, e, "TLAS re-pack");
     if (!err.empty()) return fail(c, RTAMD_ERR_BAD_INDEX, err);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -411,7 +437,7 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
     if (a.tileW > 0 && a.tileH > 0) {
         if (faithful) {
             dim3 grid((width + 7) / 8, (height + 7) / 8);
-            hipLaunchKernelGGL(rt::kFaithful, grid, dim3(64), 0, c->stream, rsc, sky, a, (const int32_t*)nullptr, 0, (float4*)nullptr);
+            hipLaunchKernelGGL(rt::kFaithful, grid, dim3(64), 0, c->stream, rsc, sky, a, (const int32_t*)nullptr, 0, (float4*)nullptr, 0);
         } else {
             hipError_t le = (a.mode == RTAMD_MODE_PT && rt::fastLaunchConfig().pool)
                                 ? rt::launchPool(c->fast, c->pool, sky, a, c->stream)
@@ -434,14 +460,16 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
             // one thread per (pixel, sample), then an in-order sum per pixel
             const size_t n = (size_t)redo * (size_t)a.spp;
             HIP_TRY(c, c->redoSamples.alloc(n));
-            hipLaunchKernelGGL(rt::kFaithful, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, rsc, sky, a,
-                               (const int32_t*)c->redoList.p, redo, c->redoSamples.p);
+            const int spread = listSpreadFor(n);
+            hipLaunchKernelGGL(rt::kFaithful, dim3((unsigned)(((n << spread) + 63) / 64)), dim3(64), 0, c->stream, rsc, sky, a,
+                               (const int32_t*)c->redoList.p, redo, c->redoSamples.p, spread);
             HIP_TRY(c, hipGetLastError());
             hipLaunchKernelGGL(rt::kSumListedSamples, dim3((redo + 63) / 64), dim3(64), 0, c->stream, a,
                                (const int32_t*)c->redoList.p, redo, (const float4*)c->redoSamples.p);
         } else {
-            hipLaunchKernelGGL(rt::kFaithful, dim3((redo + 63) / 64), dim3(64), 0, c->stream, rsc, sky, a,
-                               (const int32_t*)c->redoList.p, redo, (float4*)nullptr);
+            const int spread = listSpreadFor((size_t)redo);
+            hipLaunchKernelGGL(rt::kFaithful, dim3((unsigned)((((size_t)redo << spread) + 63) / 64)), dim3(64), 0, c->stream, rsc, sky, a,
+                               (const int32_t*)c->redoList.p, redo, (float4*)nullptr, spread);
         }
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->evStop, c->stream));

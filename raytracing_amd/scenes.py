@@ -207,6 +207,28 @@ def instanced_scene(width=1920, height=1080, instances=1250, tris_per_blas=40_00
     return buf, frame, procedural_sky()
 
 
+def scattered_scene(width=1920, height=1080, instances=5000, tris_per_blas=2000, seed=9):
+    """Instances of three meshes scattered through a cube, sizes spread over a factor of 30, with a
+    few emissive ones: a top-level tree with no preferred plane (instanced_scene is flat)."""
+    rs = np.random.RandomState(seed)
+    sys = H.BuildAccelerateStructureSystem(tlas_tree=1)
+    rings = max(4, int(round(np.sqrt(tris_per_blas / 4.0))))
+    blas = [sys.BakeBLAS(_bumpy_sphere(2 * rings, rings, 200 + k)) for k in range(3)]
+    half = 0.9 * float(instances) ** (1.0 / 3.0)
+    for i in range(instances):
+        s = float(0.1 * 30.0 ** rs.uniform(0.0, 1.0) * 0.3)
+        pos = rs.uniform(-half, half, size=3)
+        q = H.quat_axis_angle(rs.uniform(-1, 1, size=3) + 1e-3, float(rs.uniform(0, 360)))
+        col = rs.uniform(0.2, 0.9, size=3)
+        em = (3.0, 3.0, 3.0) if i % 50 == 0 else (0.0, 0.0, 0.0)
+        sys.AddEntity(blas[i % 3], H.trs(tuple(pos), q, (s, s * float(rs.uniform(0.5, 1.5)), s)), albedo=tuple(col),
+                      specular=(0.04, 0.04, 0.04), emission=em)
+    buf = sys.OnUpdate()
+    sys.close()
+    frame = look_at_camera((0.3 * half, 0.2 * half, -2.6 * half), (0.0, 0.0, 0.0), 40.0, width, height)
+    return buf, frame, procedural_sky()
+
+
 def random_soup(width=640, height=360, seed=0, meshes=4, tris_per_mesh=600, instances=40):
     """Stress scene for parity campaigns: triangle soups (random sizes, slivers, shared vertices, a few
     zero-area triangles) instanced with random rotations, non-uniform and mirrored scales, at
