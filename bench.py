@@ -122,11 +122,13 @@ def main():
     rays = 0
     kernel_ms = 0.0
     handover_ms = 0.0
+    trace_ms = 0.0
     for _ in range(args.steps):
         r = step()
         rays += r["rays"]
         kernel_ms += r["kernel_ms"]
         handover_ms += r["handover_ms"]
+        trace_ms += r["trace_ms"]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -140,9 +142,12 @@ def main():
         rays = int(rr.item())
     value = rays / elapsed / 1e6
     rays_per_launch_local = r["rays"]
-    # the production kernel alone (what rocprofv3 lists as rt::kFast), and the hand-over pass behind it
+    # the path-tracing kernel alone (what rocprofv3 lists as rt::kPool), the summation of the samples
+    # behind it, and the hand-over pass
     handover_ms_avg = handover_ms / max(1, args.steps)
-    kernel_ms_avg = kernel_ms / max(1, args.steps) - handover_ms_avg
+    kernel_ms_avg = trace_ms / max(1, args.steps)
+    sum_ms_avg = kernel_ms / max(1, args.steps) - handover_ms_avg - kernel_ms_avg
+    kernel_name = "rt::kFast<PT>" if os.environ.get("RTAMD_PIPELINE") == "persistent" or os.environ.get("RTAMD_STATS") else "rt::kPool"
 
     result = None
     if rank == 0:
@@ -168,7 +173,7 @@ def main():
                     traffic, pmc_extra = None, None
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                        "kernel": "rt::kFast<PT>", "kernel_ms": kernel_ms_avg,
+                        "kernel": kernel_name, "kernel_ms": kernel_ms_avg, "sample_sum_ms": sum_ms_avg,
                         "handover_ms": handover_ms_avg, "handover_pixels": r["handover_pixels"],
                         "algorithmic_bytes_per_launch": alg_bytes,
                         "bytes_per_ray": alg_bytes / max(1, c["rays"]),

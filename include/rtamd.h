@@ -220,6 +220,13 @@ int rtamd_set_stream(rtamd_ctx* ctx, void* hip_stream);
  * segments it traced. */
 int rtamd_last_render_stats(const rtamd_ctx* ctx, float* kernel_ms, uint64_t* ray_segments);
 
+/* Device time of the dominant kernel alone in the last rtamd_render call: in PT mode the
+ * persistent path-tracing kernel (all its launches when the frame is rendered in several
+ * batches), without the per-pixel summation of the samples and the hand-over pass; in REF
+ * mode the same as kernel_ms above.  This is the duration a kernel trace lists for that
+ * kernel.  No counterpart in the reference. */
+int rtamd_last_trace_kernel_ms(const rtamd_ctx* ctx, float* trace_ms);
+
 /* The part of that time spent in the hand-over pass (pixels the production kernel
  * could not settle itself and gave to the reference-order kernel), and how many
  * pixels that was.  No counterpart in the reference. */

@@ -16,7 +16,7 @@ _lib = None
 
 EXPORTS = ["rtamd_ctx_create", "rtamd_ctx_destroy", "rtamd_last_error_string", "rtamd_scene_upload",
            "rtamd_scene_refresh_objects", "rtamd_sky_upload", "rtamd_render", "rtamd_accum_reset",
-           "rtamd_set_stream", "rtamd_set_tlas_build", "rtamd_tlas_info", "rtamd_last_render_stats", "rtamd_last_handover_stats", "rtamd_composite_add", "rtamd_present", "rtamd_version"]
+           "rtamd_set_stream", "rtamd_set_tlas_build", "rtamd_tlas_info", "rtamd_last_render_stats", "rtamd_last_trace_kernel_ms", "rtamd_last_handover_stats", "rtamd_composite_add", "rtamd_present", "rtamd_version"]
 
 
 class BackendError(RuntimeError):
@@ -49,6 +49,7 @@ def lib():
         L.rtamd_tlas_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.rtamd_last_render_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
         L.rtamd_last_handover_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        L.rtamd_last_trace_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.rtamd_composite_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         _lib = L
     return _lib
@@ -156,8 +157,8 @@ class RayTracingPass:
 
         frame: numpy FRAME record.  Outputs may be numpy arrays, torch tensors (host or
         device) or None; when an output is True a numpy array is allocated and returned.
-        Returns dict(rgba=, ids=, t=, counters=, kernel_ms=, rays=, handover_ms=, handover_pixels=);
-        kernel_ms includes handover_ms.
+        Returns dict(rgba=, ids=, t=, counters=, kernel_ms=, rays=, trace_ms=, handover_ms=, handover_pixels=);
+        kernel_ms includes handover_ms; trace_ms is the path-tracing kernel alone.
         """
         if out_rgba is True:
             out_rgba = np.zeros((height, width, 4), dtype=np.float32)
@@ -178,9 +179,11 @@ class RayTracingPass:
         lib().rtamd_last_render_stats(self._ctx, C.byref(ms), C.byref(rays))
         hms, hpix = C.c_float(0), C.c_int32(0)
         lib().rtamd_last_handover_stats(self._ctx, C.byref(hms), C.byref(hpix))
+        tms = C.c_float(0)
+        lib().rtamd_last_trace_kernel_ms(self._ctx, C.byref(tms))
         self._check(rc)
         return dict(rgba=out_rgba, ids=out_prim_id, t=out_t, counters=cnt.as_dict() if counters else None,
-                    kernel_ms=ms.value, rays=int(rays.value), handover_ms=hms.value, handover_pixels=int(hpix.value))
+                    kernel_ms=ms.value, rays=int(rays.value), trace_ms=tms.value, handover_ms=hms.value, handover_pixels=int(hpix.value))
 
     def ExecuteDefault(self, frame, width, height, out_rgba, out_prim_id=None):
         """The plain reference dispatch: no extension block (REF mode)."""

@@ -652,7 +652,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
 struct FastLaunchConfig {
     // refillBelow / nodeMin = 0: chosen per scene in launchFast
     int blocksPerCU = 1, refillBelow = 0, nodeMin = 0, leafGroupMin = 20;
-    bool pool = false;                          // PT mode through kPool (more paths than lanes) instead of kFast
+    bool pool = true;                           // PT mode through kPool (more paths than lanes); false: kFast<PT>
     int stackLimit = kLdsStack;                 // LDS stack entries a lane may use before it moves a chunk to HBM (tests lower it)
     bool stats = false;
 };
@@ -664,8 +664,9 @@ inline FastLaunchConfig fastLaunchConfig() {
     if (const char* s = getenv("RTAMD_NODE_MIN")) { int v = atoi(s); if (v >= 1 && v <= 64) c.nodeMin = v; }
     if (const char* s = getenv("RTAMD_LEAF_GROUP_MIN")) { int v = atoi(s); if (v >= 0 && v <= 64) c.leafGroupMin = v; }
     if (const char* s = getenv("RTAMD_STACK_LIMIT")) { int v = atoi(s); if (v >= kSpillChunk + 4 && v <= kLdsStack) c.stackLimit = v; }
-    if (const char* s = getenv("RTAMD_PIPELINE")) c.pool = strcmp(s, "pool") == 0;
+    if (const char* s = getenv("RTAMD_PIPELINE")) c.pool = strcmp(s, "persistent") != 0;
     if (const char* s = getenv("RTAMD_STATS")) c.stats = atoi(s) != 0;
+    if (c.stats) c.pool = false;                // the step counters live in kFast
     return c;
 }
 

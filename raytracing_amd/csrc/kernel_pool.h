@@ -1,4 +1,5 @@
-// Path-tracing kernel with more paths than lanes (opt-in: RTAMD_PIPELINE=pool).
+// Path-tracing kernel with more paths than lanes: the production path of PT mode
+// (RTAMD_PIPELINE=persistent selects kFast<PT> instead, for comparison).
 //
 // kFast keeps one path per lane, so hit shading, sky shading, sample bookkeeping and camera-ray
 // generation all run inside the traversal kernel with whatever lanes happen to need them (about a
@@ -359,7 +360,28 @@ __global__ __launch_bounds__(256) void kPoolSum(FastScene sc, RenderArgs a, Pool
 struct PoolHost {
     DBuf<PoolRec> recs;
     DBuf<float4> sampleL, runSum;
-    void release() { recs.release(); sampleL.release(); runSum.release(); }
+    // device time of the kPool launches of the last render (the first kTimedBatches of them)
+    static constexpr int kTimedBatches = 32;
+    hipEvent_t evBegin[kTimedBatches] = {}, evEnd[kTimedBatches] = {};
+    int nTimed = 0;
+    void release() {
+        recs.release(); sampleL.release(); runSum.release();
+        for (int i = 0; i < kTimedBatches; i++) {
+            if (evBegin[i]) (void)hipEventDestroy(evBegin[i]);
+            if (evEnd[i]) (void)hipEventDestroy(evEnd[i]);
+            evBegin[i] = evEnd[i] = nullptr;
+        }
+        nTimed = 0;
+    }
+    // after the stream has been synchronised
+    float tracedMs() const {
+        float total = 0.f;
+        for (int i = 0; i < nTimed; i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, evBegin[i], evEnd[i]) == hipSuccess) total += ms;
+        }
+        return total;
+    }
 };
 
 inline size_t poolMaxPaths() {
@@ -392,7 +414,13 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         numCU = prop.multiProcessorCount;
     }
     FastLaunchConfig cfg = fastLaunchConfig();
-    chooseThresholds(cfg, fs);
+    {
+        // measured optima of the three benchmark scenes: shading is cheap here (full waves), so
+        // lanes are refilled earlier than in kFast; small scenes (same criterion as kFast's) walk on with few lanes
+        const bool allHot = fs.nBlasNodes + (size_t)fs.nTlasNodes <= (size_t)kHotNodes;
+        if (cfg.refillBelow == 0) cfg.refillBelow = allHot ? 48 : 56;
+        if (cfg.nodeMin == 0) cfg.nodeMin = allHot ? 8 : 24;
+    }
 
     FastScene sc;
     sc.nodes = fs.nodes.p; sc.inst = fs.inst.p; sc.shade = fs.shade.p;
@@ -438,6 +466,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     if ((e = ph.sampleL.ensure(workPerChunk * samplesPerBatch)) != hipSuccess) return e;
     if ((e = ph.runSum.ensure(workPerChunk)) != hipSuccess) return e;
 
+    ph.nTimed = 0;
     for (size_t t0 = 0; t0 < fs.hSuper.size(); t0 += tilesPerChunk) {
         const size_t nt = fs.hSuper.size() - t0 < tilesPerChunk ? fs.hSuper.size() - t0 : tilesPerChunk;
         for (int s0 = 0; s0 < a.spp; s0 += (int)samplesPerBatch) {
@@ -453,7 +482,14 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             if ((e = hipMemsetAsync(a.rayCount + 1, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
             long long blocksNeeded = (long long)((total + kBlockThreads - 1) / kBlockThreads);
             int grid = blocksNeeded < gridMax ? (int)blocksNeeded : gridMax;
+            const bool timed = ph.nTimed < PoolHost::kTimedBatches;
+            if (timed) {
+                const int i = ph.nTimed;
+                if (!ph.evBegin[i] && ((e = hipEventCreate(&ph.evBegin[i])) != hipSuccess || (e = hipEventCreate(&ph.evEnd[i])) != hipSuccess)) return e;
+                if ((e = hipEventRecord(ph.evBegin[i], stream)) != hipSuccess) return e;
+            }
             hipLaunchKernelGGL(kPool, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots);
+            if (timed && (e = hipEventRecord(ph.evEnd[ph.nTimed++], stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(kPoolSum, dim3((b.nWork + 255) / 256), dim3(256), 0, stream, sc, a, b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }

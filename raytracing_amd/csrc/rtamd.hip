@@ -92,7 +92,7 @@ struct rtamd_ctx {
     DevBuf<int32_t> redoList, redoCount;
     DevBuf<float4> redoSamples;
     int32_t lastRedoPixels = 0;
-    float lastKernelMs = 0.f, lastHandoverMs = 0.f;
+    float lastKernelMs = 0.f, lastHandoverMs = 0.f, lastTraceMs = 0.f;
     uint64_t lastRays = 0;
 };
 
@@ -421,6 +421,7 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
     unsigned long long hr[2] = {0, 0};
     int32_t herr = 0, redo = 0;
     float ms = 0.f, handoverMs = 0.f;
+    bool usedPool = false;
     const size_t maskWords = (npix + 31) / 32;
     HIP_TRY(c, c->redoMask.alloc(maskWords));
     HIP_TRY(c, c->redoList.alloc(npix));
@@ -439,9 +440,8 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
             dim3 grid((width + 7) / 8, (height + 7) / 8);
             hipLaunchKernelGGL(rt::kFaithful, grid, dim3(64), 0, c->stream, rsc, sky, a, (const int32_t*)nullptr, 0, (float4*)nullptr, 0);
         } else {
-            hipError_t le = (a.mode == RTAMD_MODE_PT && rt::fastLaunchConfig().pool)
-                                ? rt::launchPool(c->fast, c->pool, sky, a, c->stream)
-                                : rt::launchFast(c->fast, sky, a, c->stream);
+            usedPool = a.mode == RTAMD_MODE_PT && rt::fastLaunchConfig().pool;
+            hipError_t le = usedPool ? rt::launchPool(c->fast, c->pool, sky, a, c->stream) : rt::launchFast(c->fast, sky, a, c->stream);
             if (le != hipSuccess) return failHip(c, le, "production kernel launch");
         }
         HIP_TRY(c, hipGetLastError());
@@ -450,6 +450,7 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
     HIP_TRY(c, hipMemcpyAsync(&redo, c->redoCount.p, sizeof(redo), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipEventElapsedTime(&ms, c->evStart, c->evStop));
+    c->lastTraceMs = usedPool ? c->pool.tracedMs() : ms;
     if (redo > 0) {
         // pixels the production kernel handed over (a ray with a zero direction component, or
         // a stack deeper than its LDS stack): the reference-order kernel renders exactly those
@@ -498,6 +499,12 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
         oc->max_blas_stack = hc.maxBlasStack; oc->max_tlas_stack = hc.maxTlasStack; oc->reserved = hc.overflow;
     }
     if (herr & 1) return fail(c, RTAMD_ERR_STACK_OVERFLOW, "traversal stack overflow (scene deeper than the shader's stacks allow)");
+    return RTAMD_OK;
+}
+
+int rtamd_last_trace_kernel_ms(const rtamd_ctx* c, float* ms) {
+    if (!c || !ms) return RTAMD_ERR_INVALID_ARG;
+    *ms = c->lastTraceMs;
     return RTAMD_OK;
 }
 

@@ -312,3 +312,36 @@ def test_fifty_million_instanced_triangles(gpu_pass):
         assert _same(g["rgba"], ref["rgba"]), _report("50M", g, ref)
         assert g["rays"] == ref["rays"]
     assert (ref["ids"][..., 0] > 0).mean() > 0.2
+
+
+def test_both_path_tracing_kernels_give_the_same_image(gpu_pass, oracle, monkeypatch):
+    """PT mode runs through the path-pool kernel (more paths than lanes per wave, full-wave shading
+    passes, samples summed in order afterwards); the one-path-per-lane kernel it replaced stays
+    selectable.  Same image bit for bit, in several batches as in one, and under tile shards."""
+    from raytracing_amd import scenes
+    w, h = 320, 180
+    buf, frame, sky = scenes.random_spheres(w, h)
+    gpu_pass.SetScene(buf)
+    gpu_pass.SetSkyBox(sky)
+    kw = dict(mode=T.MODE_PT, spp=6, max_bounces=8, seed=31)
+    pool = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, **kw)
+    monkeypatch.setenv("RTAMD_PIPELINE", "persistent")
+    lane = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, **kw)
+    monkeypatch.delenv("RTAMD_PIPELINE")
+    assert _same(pool["ids"], lane["ids"]) and _same(pool["t"], lane["t"])
+    assert _same(pool["rgba"], lane["rgba"]), _report("pool vs lane", pool, lane)
+    assert pool["rays"] == lane["rays"]
+    o = oracle.render(buf, frame, w, h, sky=sky, mode=1, spp=6, max_bounces=8, seed=31, nthreads=8)
+    assert _same(pool["rgba"], o["rgba"]), _report("pool vs oracle", pool, o)
+    assert pool["rays"] == o["counters"]["rays"]
+    # sample buffer limited to 20 000 paths: 3 chunks of tiles x 6 batches of one sample
+    monkeypatch.setenv("RTAMD_POOL_MAX_PATHS", "20000")
+    small = gpu_pass.Execute(frame, w, h, out_rgba=True, **kw)
+    monkeypatch.delenv("RTAMD_POOL_MAX_PATHS")
+    assert _same(small["rgba"], pool["rgba"]) and small["rays"] == pool["rays"]
+    parts = np.zeros_like(pool["rgba"])
+    for r in range(3):
+        part = np.zeros_like(parts)
+        gpu_pass.Execute(frame, w, h, out_rgba=part, shard_rank=r, shard_count=3, **kw)
+        parts += part
+    assert _same(parts, pool["rgba"])
