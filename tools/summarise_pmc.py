@@ -4,7 +4,7 @@
     python tools/summarise_pmc.py <tag> [<tag> ...]  ->  JSON on stdout
 
 Reads gpurun_out/pmc_<tag>/*/**/*counter_collection.csv, sums every counter over the dispatches
-of the production kernel (rt::kFast<1, ...>, one launch per pass), and derives: HBM bytes per
+of the production kernel (rt::kPool, one launch per pass; RTAMD_PMC_KERNEL names another), and derives: HBM bytes per
 launch (FETCH_SIZE doubled — gfx950 reports half of wide reads — plus WRITE_SIZE, both in KiB),
 L2 hit rate, VALU lane utilisation and the share of cycles the SIMDs issue VALU work.
 """
@@ -16,13 +16,14 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL = os.environ.get("RTAMD_PMC_KERNEL", "rt::kPool(")
 
 
 def summarise(tag):
     acc = collections.defaultdict(float)
     for f in glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_{tag}", "*", "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if "rt::kFast<1" in row["Kernel_Name"]:
+            if KERNEL in row["Kernel_Name"]:
                 acc[row["Counter_Name"]] += float(row["Counter_Value"])
     d = dict(sorted(acc.items()))
     der = {}
@@ -39,7 +40,7 @@ def summarise(tag):
         cycles = d["GRBM_GUI_ACTIVE"] / 8.0
         der["simd_valu_issue_frac"] = d["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles / 4.0)
         der["l1_accesses_per_cu_cycle"] = d.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / (256.0 * cycles)
-    der["note"] = ("one launch of rt::kFast<PT> (bench.py --steps 1 --warmup 0); separate rocprofv3 --pmc passes; "
+    der["note"] = ("one launch of " + KERNEL.rstrip("(") + " (bench.py --steps 1 --warmup 0); separate rocprofv3 --pmc passes; "
                    "FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as read")
     d["derived"] = der
     return d
