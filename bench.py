@@ -168,7 +168,7 @@ def main():
                     if rec.get("workload") == args.workload and rec.get("spp") == args.spp and rec.get("width") == W:
                         traffic = rec.get("hbm_bytes_per_launch")
                         pmc_extra = {k: rec[k] for k in ("simd_valu_issue_frac", "valu_lane_utilisation", "l2_hit_rate",
-                                                         "l1_accesses_per_cu_cycle") if k in rec}
+                                                         "l1_accesses_per_cu_cycle", "wave_cycles_waiting_frac") if k in rec}
                 except Exception:
                     traffic, pmc_extra = None, None
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -451,20 +451,26 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     }
 
     // chunks of super-tiles x batches of samples, each at most `cap` paths in the sample buffer
-    const size_t cap = poolMaxPaths();
-    size_t tilesPerChunk = cap / 1024;
-    if (tilesPerChunk < 1) tilesPerChunk = 1;
-    if (tilesPerChunk > fs.hSuper.size()) tilesPerChunk = fs.hSuper.size();
-    const size_t workPerChunk = tilesPerChunk * 1024;
-    size_t samplesPerBatch = cap / workPerChunk;
-    if (samplesPerBatch < 1) samplesPerBatch = 1;
-    if (samplesPerBatch > (size_t)a.spp) samplesPerBatch = (size_t)a.spp;
+    // (16 bytes per path; when the allocation fails the cap is halved down to a million paths)
     const int gridMax = numCU * cfg.blocksPerCU;
     int poolSlots = kPoolSlots;
     if (const char* sv = getenv("RTAMD_POOL_SLOTS")) { int v = atoi(sv); if (v >= 64 && v <= kPoolSlots) poolSlots = v; }
     if ((e = ph.recs.ensure((size_t)gridMax * (kBlockThreads / 64) * kPoolSlots)) != hipSuccess) return e;
-    if ((e = ph.sampleL.ensure(workPerChunk * samplesPerBatch)) != hipSuccess) return e;
-    if ((e = ph.runSum.ensure(workPerChunk)) != hipSuccess) return e;
+    size_t tilesPerChunk = 0, workPerChunk = 0, samplesPerBatch = 0;
+    for (size_t cap = poolMaxPaths();; cap /= 2) {
+        tilesPerChunk = cap / 1024;
+        if (tilesPerChunk < 1) tilesPerChunk = 1;
+        if (tilesPerChunk > fs.hSuper.size()) tilesPerChunk = fs.hSuper.size();
+        workPerChunk = tilesPerChunk * 1024;
+        samplesPerBatch = cap / workPerChunk;
+        if (samplesPerBatch < 1) samplesPerBatch = 1;
+        if (samplesPerBatch > (size_t)a.spp) samplesPerBatch = (size_t)a.spp;
+        e = ph.sampleL.ensure(workPerChunk * samplesPerBatch);
+        if (e == hipSuccess) e = ph.runSum.ensure(workPerChunk);
+        if (e == hipSuccess) break;
+        if (e != hipErrorOutOfMemory || cap <= ((size_t)1 << 20)) return e;
+        (void)hipGetLastError();
+    }
 
     ph.nTimed = 0;
     for (size_t t0 = 0; t0 < fs.hSuper.size(); t0 += tilesPerChunk) {
