@@ -294,3 +294,25 @@ def test_traversal_stack_overflow_area(gpu_pass, oracle, scene_mesh_small, monke
     assert np.array_equal(g["ids"], o["ids"]) and np.array_equal(g["t"], o["t"], equal_nan=True)
     assert np.array_equal(g["rgba"], o["rgba"])
     assert g["rays"] == o["counters"]["rays"]
+
+
+def test_sample_shards_sum_to_the_whole(gpu_pass, oracle, scene_random_small):
+    """Sample sharding as the multi-GPU bench does it: rank r renders samples [r*spp, (r+1)*spp) as raw
+    sums (RTAMD_FLAG_OUTPUT_SUM); each shard equals the oracle's bit for bit, and the shards added
+    and divided agree with the single render of all samples to fp32 summation-order tolerance."""
+    buf, frame, sky = scene_random_small
+    w, h = 96, 54
+    gpu_pass.SetScene(buf)
+    gpu_pass.SetSkyBox(sky)
+    kw = dict(mode=T.MODE_PT, max_bounces=4, seed=9)
+    total = np.zeros((h, w, 4), dtype=np.float32)
+    for r in range(4):
+        part = gpu_pass.Execute(frame, w, h, out_rgba=True, spp=3, sample_offset=3 * r, flags=T.FLAG_OUTPUT_SUM, **kw)["rgba"]
+        o = oracle.render(buf, frame, w, h, sky=sky, mode=1, spp=3, sample_offset=3 * r, max_bounces=4, seed=9, flags=T.FLAG_OUTPUT_SUM,
+                          want_ids=False, want_t=False)["rgba"]
+        assert np.array_equal(part, o), r
+        total += part
+    assert (total[..., 3] == 12).all()
+    mean = total[..., :3] / total[..., 3:4]
+    whole = gpu_pass.Execute(frame, w, h, out_rgba=True, spp=12, **kw)["rgba"]
+    np.testing.assert_allclose(mean, whole[..., :3], rtol=2e-6, atol=1e-6)      # same 12 samples, added in a different order
