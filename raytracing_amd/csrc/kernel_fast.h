@@ -1,5 +1,6 @@
-// Production path: GPU-side scene layout, its construction at upload time, and the
-// persistent traversal + shading kernel.
+// Production path: GPU-side scene layout, its construction at upload time, and the persistent
+// one-path-per-lane kernel kFast (REF mode, the primary-id pass, and PT mode when asked for; PT
+// mode normally runs through kPool, kernel_pool.h, which shares the traversal code below).
 //
 // What the kernel must reproduce is fixed by Assets/Shaders/RayTracingShader.compute:
 // the closest front-facing triangle along each ray with the arithmetic of Trisection
