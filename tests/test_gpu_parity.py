@@ -189,13 +189,13 @@ def device_tlas(gpu_pass):
     gpu_pass.SetTlasBuild("auto")
 
 
-@pytest.mark.parametrize("instances", [1, 2, 3, 5, 64, 3000])
+@pytest.mark.parametrize("instances", [1, 2, 3, 5, 64, 3000, 20000])
 def test_tlas_built_on_the_device(device_tlas, oracle, instances):
     """The library's private tree over the instances built by the GPU kernels (Morton order, binary
     radix tree, collapse to 4-wide nodes): same image as the oracle bit for bit, whatever the tree."""
     from raytracing_amd import scenes
     w, h = 96, 54
-    buf, frame, sky = scenes.instanced_scene(w, h, instances=instances, tris_per_blas=300, tlas_tree=instances % 2)
+    buf, frame, sky = scenes.instanced_scene(w, h, instances=instances, tris_per_blas=300, tlas_tree=1 if instances > 1200 else instances % 2)
     device_tlas.SetScene(buf)
     device_tlas.SetSkyBox(sky)
     info = device_tlas.TlasInfo()
