@@ -13,12 +13,16 @@
 //
 // Builder: top-down binned SAH (32 bins, three axes) on box centroids; a node takes the
 // range, splits it, then keeps splitting the part with the largest area * count until it
-// has four parts (or every part fits a leaf).
+// has four parts (or every part fits a leaf).  Large subtrees are built by threads of their own
+// (disjoint item ranges, a private node array spliced into the parent's afterwards); the tree does
+// not depend on how many threads ran.
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace rt {
@@ -45,11 +49,15 @@ inline float halfArea(const float lo[3], const float hi[3]) {
     return dx * dy + dy * dz + dz * dx;
 }
 
+constexpr int kSpawnMin = 16384;     // items from which a subtree is worth a thread
+constexpr int kMaxThreads = 8;
+
 struct Builder {
     const BuildBox* boxes;
-    std::vector<Item> items;
+    Item* items;
     WideTree* out;
     int maxLeaf;
+    std::atomic<int>* threads;       // builder threads running, shared by the whole build
 
     void bounds(int lo, int hi, float blo[3], float bhi[3]) const {
         for (int k = 0; k < 3; k++) { blo[k] = __builtin_inff(); bhi[k] = -__builtin_inff(); }
@@ -110,12 +118,12 @@ struct Builder {
         if (bestAxis < 0) return lo + n / 2;     // all centroids coincide
         const float cmin = clo[bestAxis];
         const float scale = kBins / (chi[bestAxis] - clo[bestAxis]);
-        auto it = std::partition(items.begin() + lo, items.begin() + hi, [&](const Item& p) {
+        auto it = std::partition(items + lo, items + hi, [&](const Item& p) {
             int b = (int)((p.c[bestAxis] - cmin) * scale);
             b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
             return b <= bestBin;
         });
-        int mid = (int)(it - items.begin());
+        int mid = (int)(it - items);
         if (mid == lo || mid == hi) mid = lo + n / 2;
         return mid;
     }
@@ -165,8 +173,44 @@ struct Builder {
                 else for (int k = 0; k < 3; k++) { nd.lo[s][k] = __builtin_inff(); nd.hi[s][k] = __builtin_inff(); }
             }
         }
-        for (int s = 0; s < ns; s++)
-            if (childNode[s] >= 0) buildNode(childNode[s], segs[s].lo, segs[s].hi, depth + 1);
+        // subtrees: the large ones on threads of their own while this thread does the rest
+        struct Job { std::thread th; WideTree tree; int child; };
+        Job jobs[4];
+        int nJobs = 0;
+        for (int s = 0; s < ns; s++) {
+            if (childNode[s] < 0) continue;
+            const int n = segs[s].hi - segs[s].lo;
+            if (n >= kSpawnMin && threads->fetch_add(1) < kMaxThreads - 1) {
+                Job& j = jobs[nJobs++];
+                j.child = childNode[s];
+                j.tree.nodes.emplace_back();
+                const int jlo = segs[s].lo, jhi = segs[s].hi;
+                WideTree* jt = &j.tree;
+                j.th = std::thread([this, jt, jlo, jhi, depth]() {
+                    Builder sub = *this;
+                    sub.out = jt;
+                    sub.buildNode(0, jlo, jhi, depth + 1);
+                    threads->fetch_sub(1);
+                });
+            } else {
+                if (n >= kSpawnMin) threads->fetch_sub(1);
+                buildNode(childNode[s], segs[s].lo, segs[s].hi, depth + 1);
+            }
+        }
+        for (int k = 0; k < nJobs; k++) {
+            jobs[k].th.join();
+            // node 0 of the private array is the child itself, the others are appended
+            const WideTree& t = jobs[k].tree;
+            const int32_t base = (int32_t)out->nodes.size() - 1;
+            out->nodes.resize(out->nodes.size() + t.nodes.size() - 1);
+            for (size_t i = 0; i < t.nodes.size(); i++) {
+                WideTree::Node nd = t.nodes[i];
+                for (int s = 0; s < 4; s++)
+                    if (nd.child[s] > 0) nd.child[s] += base;
+                out->nodes[i == 0 ? (size_t)jobs[k].child : (size_t)base + i] = nd;
+            }
+            if (t.depth > out->depth) out->depth = t.depth;
+        }
     }
 };
 
@@ -178,13 +222,16 @@ inline void buildWideTree(const BuildBox* boxes, int n, int maxLeaf, WideTree& o
     out.order.clear();
     out.depth = 0;
     widebvh::Builder b;
+    std::vector<widebvh::Item> items((size_t)n);
+    std::atomic<int> threads(0);
     b.boxes = boxes;
+    b.items = items.data();
     b.out = &out;
     b.maxLeaf = maxLeaf;
-    b.items.resize(n);
+    b.threads = &threads;
     for (int i = 0; i < n; i++) {
-        for (int k = 0; k < 3; k++) b.items[i].c[k] = (boxes[i].lo[k] + boxes[i].hi[k]) * 0.5f;
-        b.items[i].index = i;
+        for (int k = 0; k < 3; k++) items[i].c[k] = (boxes[i].lo[k] + boxes[i].hi[k]) * 0.5f;
+        items[i].index = i;
     }
     out.nodes.emplace_back();
     if (n > 0) b.buildNode(0, 0, n, 1);
@@ -196,7 +243,7 @@ inline void buildWideTree(const BuildBox* boxes, int n, int maxLeaf, WideTree& o
         }
     }
     out.order.resize(n);
-    for (int i = 0; i < n; i++) out.order[i] = b.items[i].index;
+    for (int i = 0; i < n; i++) out.order[i] = items[i].index;
 }
 
 }  // namespace rt
