@@ -4,7 +4,7 @@
 // kFast keeps one path per lane, so hit shading, sky shading, sample bookkeeping and camera-ray
 // generation all run inside the traversal kernel with whatever lanes happen to need them (about a
 // third of the wave each), and that code is 40 % of the kernel's instructions.  Here a wave owns
-// kPoolSlots paths, each in a 128-byte record in HBM (L2 / Infinity-Cache resident: 24 KiB per
+// kPoolSlots paths, each in a 128-byte record in HBM (L2 / Infinity-Cache resident: 16 KiB per
 // wave).  A lane only traverses: when its ray is done it writes the hit into the path's record,
 // queues the path for shading (a per-wave queue in LDS) and takes the next ready ray from a second
 // per-wave queue.  When 64 hits have collected, the whole wave shades them — one path per lane,
@@ -38,10 +38,10 @@ struct alignas(128) PoolRec {
 static_assert(sizeof(PoolRec) == 128, "one record per 128-byte line");
 
 constexpr int32_t kPoolMiss = -1, kPoolUnsettled = -3, kPoolFresh = -4;
-constexpr int kPoolSlots = 192;      // paths per wave
-constexpr int kPoolQueue = 256;      // entries per queue (power of two >= kPoolSlots)
+constexpr int kPoolSlots = 128;      // paths per wave
+constexpr int kPoolQueue = 128;      // entries per queue (power of two >= kPoolSlots)
 constexpr int kPoolChunk = 512;      // path indices a wave takes from the batch at a time
-constexpr int kPoolHotNodes = 320;   // LDS: 96 KiB stacks + 16 KiB queues + 45 KiB nodes
+constexpr int kPoolHotNodes = 376;   // LDS: 96 KiB stacks + 8 KiB queues + 53 KiB nodes
 
 struct PoolBatch {
     PoolRec* recs;                // [waves of the grid][kPoolSlots]
