@@ -195,6 +195,11 @@ def test_error_codes(scene_few):
     with pytest.raises(backend.BackendError) as ei:
         p.Execute(frame, 64, 36, out_rgba=True)
     assert ei.value.code == -6                                   # no scene: the reference skips the dispatch
+    with pytest.raises(backend.BackendError) as ei:
+        p.TlasInfo()
+    assert ei.value.code == -6
+    assert backend.lib().rtamd_set_tlas_build(p._ctx, 3) == -1 and backend.lib().rtamd_set_tlas_build(p._ctx, -1) == -1
+    assert backend.lib().rtamd_set_tlas_build(None, 0) == -1 and backend.lib().rtamd_last_trace_kernel_ms(p._ctx, None) == -1
     bad = H.SceneBuffers(buf.tlas, buf.blas_offsets, buf.blas, buf.vertices_offsets, buf.vertices, buf.triangles_offsets,
                          buf.triangles, buf.objects)
     bad.triangles = buf.triangles.copy()
