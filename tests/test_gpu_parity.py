@@ -345,3 +345,48 @@ def test_both_path_tracing_kernels_give_the_same_image(gpu_pass, oracle, monkeyp
         gpu_pass.Execute(frame, w, h, out_rgba=part, shard_rank=r, shard_count=3, **kw)
         parts += part
     assert _same(parts, pool["rgba"])
+
+
+def test_random_frame_sizes_and_parameters(gpu_pass, oracle):
+    """Seeded random combinations of odd frame sizes, tile rectangles, shard splits, sample counts and
+    offsets, bounce limits and flags, in both modes, against the oracle with the same parameters
+    (pixels outside the rectangle / shard keep the sentinel the buffer was filled with)."""
+    from raytracing_amd import scenes
+    rs = np.random.RandomState(77)
+    for case in range(24):
+        w, h = int(rs.randint(1, 130)), int(rs.randint(1, 80))
+        buf, frame, sky = scenes.few_spheres(w, h) if case % 2 == 0 else scenes.random_spheres(w, h)
+        gpu_pass.SetScene(buf)
+        gpu_pass.SetSkyBox(sky if case % 5 else None)
+        mode = T.MODE_PT if case % 3 else T.MODE_REF
+        kw = dict(mode=mode)
+        if mode == T.MODE_PT:
+            kw.update(spp=int(rs.randint(1, 6)), max_bounces=int(rs.randint(0, 5)), seed=int(rs.randint(0, 2 ** 31)),
+                      sample_offset=int(rs.randint(0, 100)))
+            flags = 0
+            if rs.rand() < 0.3:
+                flags |= T.FLAG_NO_JITTER
+            if rs.rand() < 0.3:
+                flags |= T.FLAG_OUTPUT_SUM
+            kw["flags"] = flags
+        tile = shard = None
+        if rs.rand() < 0.5:
+            tx, ty = int(rs.randint(0, w)), int(rs.randint(0, h))
+            tile = (tx, ty, int(rs.randint(1, w - tx + 8)), int(rs.randint(1, h - ty + 8)))
+            kw.update(tile_x=tile[0], tile_y=tile[1], tile_w=tile[2], tile_h=tile[3])
+        if rs.rand() < 0.4:
+            n = int(rs.randint(2, 5))
+            shard = (int(rs.randint(0, n)), n)
+            kw.update(shard_rank=shard[0], shard_count=shard[1])
+        g_rgba = np.full((h, w, 4), 7.0, dtype=np.float32)
+        g_ids = np.full((h, w, 2), -9, dtype=np.int32)
+        g = gpu_pass.Execute(frame, w, h, out_rgba=g_rgba, out_prim_id=g_ids, **kw)
+        o_rgba = np.full((h, w, 4), 7.0, dtype=np.float32)
+        o_ids = np.full((h, w, 2), -9, dtype=np.int32)
+        o = oracle.render(buf, frame, w, h, sky=sky if case % 5 else None, mode=mode, spp=kw.get("spp", 1),
+                          max_bounces=kw.get("max_bounces", 0), seed=kw.get("seed", 0), sample_offset=kw.get("sample_offset", 0),
+                          flags=kw.get("flags", 0), tile=tile, shard=shard, rgba=o_rgba, ids=o_ids, want_t=False)
+        what = (case, w, h, kw)
+        assert _same(g_ids, o_ids), what
+        assert _same(g_rgba, o_rgba), what
+        assert g["rays"] == o["counters"]["rays"], what
