@@ -49,8 +49,14 @@ def cpu_baseline(buf, frame, sky, width, height, spp, bounces, seed):
                  want_ids=False, want_t=False)
     dt = time.time() - t0
     c = r["counters"]
+    # and one core alone on 2 spp of the same frame (a few seconds)
+    t1 = time.time()
+    r1 = O.render(buf, frame, sw, sh, sky=sky, mode=1, spp=min(2, sspp), max_bounces=bounces, seed=seed, nthreads=1,
+                  want_ids=False, want_t=False)
+    dt1 = time.time() - t1
     return {"value": c["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"{sw}x{sh}, {sspp} spp, {bounces} bounces of the same scene and camera ({c['rays']} ray segments, {dt:.1f} s)",
+            "single_core_value": r1["counters"]["rays"] / dt1 / 1e6,
             "nodes_per_ray": c["nodes"] / max(1, c["rays"]), "tris_per_ray": c["tris"] / max(1, c["rays"])}
 
 
