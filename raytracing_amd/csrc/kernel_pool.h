@@ -40,7 +40,7 @@ static_assert(sizeof(PoolRec) == 128, "one record per 128-byte line");
 constexpr int32_t kPoolMiss = -1, kPoolUnsettled = -3, kPoolFresh = -4;
 constexpr int kPoolSlots = 128;      // paths per wave
 constexpr int kPoolQueue = 128;      // entries per queue (power of two >= kPoolSlots)
-constexpr int kPoolChunk = 512;      // path indices a wave takes from the batch at a time
+constexpr int kPoolChunk = 512;      // path indices a wave takes from the batch at a time (fewer when the batch is small)
 constexpr int kPoolHotNodes = 376;   // LDS: 96 KiB stacks + 8 KiB queues + 53 KiB nodes
 
 struct PoolBatch {
@@ -54,6 +54,7 @@ struct PoolBatch {
     int32_t nSamples;             // samples in the batch
     int32_t firstBatch, lastBatch;
     int32_t hotTlas, hotBlas;     // hot-node ranges for kPoolHotNodes
+    int32_t chunk;                // path indices a wave takes at a time
 };
 
 // work item -> pixel; false when the item lies outside the image or the requested rectangle
@@ -227,14 +228,14 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             {
                 const unsigned long long me = __ballot(ended);
                 if (me != 0ull && !noMoreWork) {
-                    // path indices come in chunks of kPoolChunk per wave (one atomic per chunk); a lane
+                    // path indices come in chunks of b.chunk per wave (one atomic per chunk); a lane
                     // that finds the chunk used up keeps a placeholder and asks again in the next pass
                     if (pathNext == pathEnd) {
                         unsigned long long got = 0;
-                        if (lane == 0) got = atomicAdd(b.next, (unsigned long long)kPoolChunk);
+                        if (lane == 0) got = atomicAdd(b.next, (unsigned long long)b.chunk);
                         got = __shfl(got, 0, 64);
                         if (got >= totalPaths) noMoreWork = true;
-                        else { pathNext = got; pathEnd = totalPaths - got < (unsigned long long)kPoolChunk ? totalPaths : got + kPoolChunk; }
+                        else { pathNext = got; pathEnd = totalPaths - got < (unsigned long long)b.chunk ? totalPaths : got + b.chunk; }
                     }
                     const unsigned long long base = pathNext;
                     const unsigned long long avail = pathEnd - pathNext;
@@ -488,6 +489,12 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             if ((e = hipMemsetAsync(a.rayCount + 1, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
             long long blocksNeeded = (long long)((total + kBlockThreads - 1) / kBlockThreads);
             int grid = blocksNeeded < gridMax ? (int)blocksNeeded : gridMax;
+            {
+                // about eight chunks per wave even in a small batch, so that no wave ends up with twice the work of another
+                const unsigned long long perWave = total / ((unsigned long long)grid * (kBlockThreads / 64) * 8ull);
+                b.chunk = perWave >= (unsigned long long)kPoolChunk ? kPoolChunk : (perWave < 64ull ? 64 : (int)(perWave / 64ull) * 64);
+                if (const char* cv = getenv("RTAMD_POOL_CHUNK")) { int v = atoi(cv); if (v >= 1 && v <= 65536) b.chunk = v; }
+            }
             const bool timed = ph.nTimed < PoolHost::kTimedBatches;
             if (timed) {
                 const int i = ph.nTimed;
