@@ -84,3 +84,23 @@ def test_no_gpu_means_loud_failure():
     rc = backend.lib().rtamd_ctx_create(0, C.byref(ctx))
     assert rc == -7 and not ctx.value
     assert b"no CPU fallback" in backend.lib().rtamd_last_error_string(None)
+
+
+def test_csharp_shim_imports_only_declared_functions_with_the_declared_arity():
+    """The P/Invoke declarations a maintainer would drop into the Unity project name functions of
+    include/rtamd.h and pass as many arguments as the header declares (the shim cannot be compiled
+    here: no C# toolchain)."""
+    header = open(os.path.join(ROOT, "include", "rtamd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = {}
+    for m in re.finditer(r"\b(rtamd_\w+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S):
+        args = m.group(2).strip()
+        declared[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    shim = open(os.path.join(ROOT, "csharp", "RayTracingPassNative.cs")).read()
+    shim = re.sub(r"//[^\n]*", "", shim)
+    imports = re.findall(r"\[DllImport\(Lib\)\]\s*public static extern \w+\s+(rtamd_\w+)\s*\(([^;]*?)\)\s*;", shim, flags=re.S)
+    assert len(imports) >= 10
+    for name, args in imports:
+        assert name in declared, name
+        n = 0 if not args.strip() else args.count(",") + 1
+        assert n == declared[name], (name, n, declared[name])
