@@ -36,7 +36,8 @@ struct FastScene {
     int32_t tlasRoot;            // index of the TLAS root in nodes
     // nodes kept in LDS by every workgroup: [0, hotTlas) and [blasBase, blasBase + hotBlas)
     int32_t hotTlas, blasBase, hotBlas;
-    int32_t* stackSpill;         // overflow of the LDS traversal stacks: [kSpillMax][threads of the grid]
+    int32_t* stackSpill;         // overflow of the LDS traversal stacks: [spillMax][threads of the grid]
+    int32_t spillMax;            // overflow entries per lane (0: none, a deeper stack hands its pixel over at once)
 };
 
 template <typename T>

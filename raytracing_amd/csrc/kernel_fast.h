@@ -681,7 +681,15 @@ inline void chooseThresholds(FastLaunchConfig& cfg, const FastSceneHost& fs) {
     if (cfg.nodeMin == 0) cfg.nodeMin = allHot ? 8 : 16;
 }
 
-inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs& a, hipStream_t stream) {
+// Device memory the caller lends to one launch in place of the context's growable buffers (the
+// allocation-free entry point): room for the tile list; there is no stack overflow area then,
+// a stack deeper than LDS hands its pixel to the reference-order kernel at once.
+struct LaunchScratch {
+    int32_t* superTiles;
+    int32_t superCap;
+};
+
+inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs& a, hipStream_t stream, const LaunchScratch* lent = nullptr) {
     // 32x32 tiles intersecting the rectangle and owned by this shard
     int tilesX = (a.width + 31) / 32;
     fs.hSuper.clear();
@@ -693,7 +701,11 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
             fs.hSuper.push_back(id);
         }
     if (fs.hSuper.empty()) return hipSuccess;
-    hipError_t e = fs.superTiles.put(fs.hSuper, stream);
+    hipError_t e;
+    if (lent) {
+        if (fs.hSuper.size() > (size_t)lent->superCap) return hipErrorInvalidValue;
+        e = hipMemcpyAsync(lent->superTiles, fs.hSuper.data(), fs.hSuper.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+    } else e = fs.superTiles.put(fs.hSuper, stream);
     if (e != hipSuccess) return e;
 
     static int numCU = 0;
@@ -713,10 +725,15 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
 
     FastScene sc;
     sc.nodes = fs.nodes.p; sc.inst = fs.inst.p; sc.shade = fs.shade.p;
-    sc.tris = fs.tris.p; sc.nrms = fs.nrms.p; sc.triOrig = fs.triOrig.p; sc.superTiles = fs.superTiles.p; sc.nSuperTiles = (int)fs.hSuper.size();
+    sc.tris = fs.tris.p; sc.nrms = fs.nrms.p; sc.triOrig = fs.triOrig.p; sc.nSuperTiles = (int)fs.hSuper.size();
     sc.tlasRoot = fs.tlasRoot;
-    if ((e = fs.stackSpill.ensure((size_t)kSpillMax * (size_t)(numCU * cfg.blocksPerCU) * kBlockThreads)) != hipSuccess) return e;
-    sc.stackSpill = fs.stackSpill.p;
+    if (lent) { sc.superTiles = lent->superTiles; sc.stackSpill = nullptr; sc.spillMax = 0; }
+    else {
+        sc.superTiles = fs.superTiles.p;
+        if ((e = fs.stackSpill.ensure((size_t)kSpillMax * (size_t)(numCU * cfg.blocksPerCU) * kBlockThreads)) != hipSuccess) return e;
+        sc.stackSpill = fs.stackSpill.p;
+        sc.spillMax = kSpillMax;
+    }
     // LDS budget: the whole TLAS if it leaves half of the room (or more, when the BLAS trees are small) to the BLAS tops
     {
         const int nb = fs.nBlasNodes < (size_t)kHotNodes ? (int)fs.nBlasNodes : kHotNodes;
@@ -736,7 +753,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         // the work-queue head and ray counter are shared: reset them between the passes
         if ((e = hipMemsetAsync(a.rayCount, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
     }
-    if (cfg.stats && a.mode == RTAMD_MODE_PT) {
+    if (cfg.stats && a.mode == RTAMD_MODE_PT && !lent) {
         // diagnostic build: per-phase execution counts and active lanes, printed to stderr
         if ((e = fs.stats.ensure(16)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(fs.stats.p, 0, 16 * sizeof(unsigned long long), stream)) != hipSuccess) return e;

@@ -361,18 +361,26 @@ __global__ __launch_bounds__(256) void kPoolSum(FastScene sc, RenderArgs a, Pool
 struct PoolHost {
     DBuf<PoolRec> recs;
     DBuf<float4> sampleL, runSum;
-    // device time of the kPool launches of the last render (the first kTimedBatches of them)
-    static constexpr int kTimedBatches = 32;
-    hipEvent_t evBegin[kTimedBatches] = {}, evEnd[kTimedBatches] = {};
+    // device time of the kPool launches of the last render: one pair of events per launch
+    std::vector<hipEvent_t> evBegin, evEnd;
     int nTimed = 0;
     void release() {
         recs.release(); sampleL.release(); runSum.release();
-        for (int i = 0; i < kTimedBatches; i++) {
-            if (evBegin[i]) (void)hipEventDestroy(evBegin[i]);
-            if (evEnd[i]) (void)hipEventDestroy(evEnd[i]);
-            evBegin[i] = evEnd[i] = nullptr;
-        }
+        for (hipEvent_t ev : evBegin) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : evEnd) (void)hipEventDestroy(ev);
+        evBegin.clear(); evEnd.clear();
         nTimed = 0;
+    }
+    // events of launch i (created on first use)
+    hipError_t eventsFor(int i) {
+        while ((int)evBegin.size() <= i) {
+            hipEvent_t b = nullptr, e = nullptr;
+            hipError_t err = hipEventCreate(&b);
+            if (err == hipSuccess && (err = hipEventCreate(&e)) != hipSuccess) (void)hipEventDestroy(b);
+            if (err != hipSuccess) return err;
+            evBegin.push_back(b); evEnd.push_back(e);
+        }
+        return hipSuccess;
     }
     // after the stream has been synchronised
     float tracedMs() const {
@@ -394,6 +402,7 @@ inline size_t poolMaxPaths() {
 // PT-mode render of the pixels selected by `a` (radiance only: the identity of the primary
 // hit comes from kFast<kModePrimary>, launched here first when asked for).
 inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, const RenderArgs& a, hipStream_t stream) {
+    ph.nTimed = 0;
     int tilesX = (a.width + 31) / 32;
     fs.hSuper.clear();
     int sx0 = a.tileX / 32, sx1 = (a.tileX + a.tileW - 1) / 32, sy0 = a.tileY / 32, sy1 = (a.tileY + a.tileH - 1) / 32;
@@ -429,6 +438,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     sc.tlasRoot = fs.tlasRoot;
     if ((e = fs.stackSpill.ensure((size_t)kSpillMax * (size_t)(numCU * cfg.blocksPerCU) * kBlockThreads)) != hipSuccess) return e;
     sc.stackSpill = fs.stackSpill.p;
+    sc.spillMax = kSpillMax;
     sc.blasBase = fs.tlasReserve;
     auto hotRanges = [&](int budget, int32_t& hotTlas, int32_t& hotBlas) {
         const int nb = fs.nBlasNodes < (size_t)budget ? (int)fs.nBlasNodes : budget;
@@ -473,7 +483,6 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         (void)hipGetLastError();
     }
 
-    ph.nTimed = 0;
     for (size_t t0 = 0; t0 < fs.hSuper.size(); t0 += tilesPerChunk) {
         const size_t nt = fs.hSuper.size() - t0 < tilesPerChunk ? fs.hSuper.size() - t0 : tilesPerChunk;
         for (int s0 = 0; s0 < a.spp; s0 += (int)samplesPerBatch) {
@@ -495,14 +504,10 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
                 b.chunk = perWave >= (unsigned long long)kPoolChunk ? kPoolChunk : (perWave < 64ull ? 64 : (int)(perWave / 64ull) * 64);
                 if (const char* cv = getenv("RTAMD_POOL_CHUNK")) { int v = atoi(cv); if (v >= 1 && v <= 65536) b.chunk = v; }
             }
-            const bool timed = ph.nTimed < PoolHost::kTimedBatches;
-            if (timed) {
-                const int i = ph.nTimed;
-                if (!ph.evBegin[i] && ((e = hipEventCreate(&ph.evBegin[i])) != hipSuccess || (e = hipEventCreate(&ph.evEnd[i])) != hipSuccess)) return e;
-                if ((e = hipEventRecord(ph.evBegin[i], stream)) != hipSuccess) return e;
-            }
+            if ((e = ph.eventsFor(ph.nTimed)) != hipSuccess) return e;
+            if ((e = hipEventRecord(ph.evBegin[ph.nTimed], stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(kPool, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots);
-            if (timed && (e = hipEventRecord(ph.evEnd[ph.nTimed++], stream)) != hipSuccess) return e;
+            if ((e = hipEventRecord(ph.evEnd[ph.nTimed++], stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(kPoolSum, dim3((b.nWork + 255) / 256), dim3(256), 0, stream, sc, a, b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
