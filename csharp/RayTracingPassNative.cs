@@ -34,6 +34,8 @@ namespace Script.RayTracing
         [DllImport(Lib)] public static extern int rtamd_tlas_info(IntPtr ctx, out int nodes, out int levels, out int builtOnDevice);
         [DllImport(Lib)] public static extern int rtamd_sky_upload(IntPtr ctx, void* rgba32f, int w, int h);
         [DllImport(Lib)] public static extern int rtamd_render(IntPtr ctx, FrameCBuffer* frame, ExtParams* ext, int w, int h, void* outRgba, void* outPrimId);
+        // rtamd_render without any device allocation (outputs must be device memory): for callers under HIP graph capture or in a serving loop
+        [DllImport(Lib)] public static extern int rtamd_render_noalloc(IntPtr ctx, FrameCBuffer* frame, ExtParams* ext, int w, int h, void* outRgbaDevice, void* outPrimIdDevice);
         [DllImport(Lib)] public static extern int rtamd_accum_reset(IntPtr ctx);
         [DllImport(Lib)] public static extern int rtamd_composite_add(IntPtr ctx, void* srcRgba32f, void* dstRgba8, int w, int h);
         [DllImport(Lib)] public static extern int rtamd_present(IntPtr ctx, void* srcRgba32f, void* dstRgba8, int w, int h, int tonemap, float exposure, float gamma);

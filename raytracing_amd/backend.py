@@ -15,7 +15,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "lib
 _lib = None
 
 EXPORTS = ["rtamd_ctx_create", "rtamd_ctx_destroy", "rtamd_last_error_string", "rtamd_scene_upload",
-           "rtamd_scene_refresh_objects", "rtamd_sky_upload", "rtamd_render", "rtamd_accum_reset",
+           "rtamd_scene_refresh_objects", "rtamd_sky_upload", "rtamd_render", "rtamd_render_noalloc", "rtamd_accum_reset",
            "rtamd_set_stream", "rtamd_set_tlas_build", "rtamd_tlas_info", "rtamd_last_render_stats", "rtamd_last_trace_kernel_ms", "rtamd_last_handover_stats", "rtamd_composite_add", "rtamd_present", "rtamd_version"]
 
 
@@ -43,6 +43,7 @@ def lib():
         L.rtamd_scene_refresh_objects.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         L.rtamd_sky_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.rtamd_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(T.ExtParams), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.rtamd_render_noalloc.argtypes = L.rtamd_render.argtypes
         L.rtamd_accum_reset.argtypes = [C.c_void_p]
         L.rtamd_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.rtamd_set_tlas_build.argtypes = [C.c_void_p, C.c_int32]
@@ -152,7 +153,14 @@ class RayTracingPass:
             setattr(e, k, v)
         return e
 
-    def Execute(self, frame, width, height, out_rgba=None, out_prim_id=None, out_t=None, counters=False, **ext_kw):
+    def ExecuteNoAlloc(self, frame, width, height, out_rgba=None, out_prim_id=None, out_t=None, **ext_kw):
+        """Execute through rtamd_render_noalloc: outputs must be device memory (torch tensors or
+        raw device pointers); the call allocates nothing on the GPU."""
+        return self.Execute(frame, width, height, out_rgba=out_rgba, out_prim_id=out_prim_id, out_t=out_t,
+                            _entry="rtamd_render_noalloc", **ext_kw)
+
+    def Execute(self, frame, width, height, out_rgba=None, out_prim_id=None, out_t=None, counters=False,
+                _entry="rtamd_render", **ext_kw):
         """Render one frame.
 
         frame: numpy FRAME record.  Outputs may be numpy arrays, torch tensors (host or
@@ -174,7 +182,7 @@ class RayTracingPass:
         if out_t is not None:
             e.out_t = _ptr(out_t)
         frame = np.ascontiguousarray(frame, dtype=T.FRAME)
-        rc = lib().rtamd_render(self._ctx, _ptr(frame), C.byref(e), width, height, _ptr(out_rgba), _ptr(out_prim_id))
+        rc = getattr(lib(), _entry)(self._ctx, _ptr(frame), C.byref(e), width, height, _ptr(out_rgba), _ptr(out_prim_id))
         ms, rays = C.c_float(0), C.c_uint64(0)
         lib().rtamd_last_render_stats(self._ctx, C.byref(ms), C.byref(rays))
         hms, hpix = C.c_float(0), C.c_int32(0)

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -49,10 +50,52 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+// ---- working memory of the allocation-free entry point (rtamd_render_noalloc) ----------------
+// One fixed array per GPU, held from library load to process exit; every call on a GPU uses that
+// GPU's copy.  Layout (byte offsets, each a multiple of 256):
+constexpr int64_t kNaMaxPixels = 3840ll * 2160ll;   // largest frame
+constexpr int32_t kNaMaxTiles = 8192;               // 32x32 tiles of the largest frame (120 x 68 = 8160)
+constexpr int32_t kNaRedoCap = 65536;               // pixels the production kernel may hand to the reference-order kernel
+constexpr int32_t kNaSampleCap = 262144;            // samples (float4) of one piece of the hand-over pass; also the largest spp
+constexpr size_t kNaOffCounters = 0;                // rt::DevCounters (64 B)
+constexpr size_t kNaOffRayCount = 64;               // ray counter, work-queue head (2 x 8 B)
+constexpr size_t kNaOffErrorFlag = 80;
+constexpr size_t kNaOffRedoCount = 84;
+constexpr size_t kNaOffRedoMask = 256;              // one bit per pixel
+constexpr size_t kNaOffRedoList = kNaOffRedoMask + (size_t)(kNaMaxPixels / 32) * 4;
+constexpr size_t kNaOffSuperTiles = kNaOffRedoList + (size_t)kNaRedoCap * 4;
+constexpr size_t kNaOffSamples = kNaOffSuperTiles + (size_t)kNaMaxTiles * 4;
+constexpr size_t kNaBytes = kNaOffSamples + (size_t)kNaSampleCap * 16;      // 5 526 272 bytes
+static_assert(kNaOffRedoList % 256 == 0 && kNaOffSuperTiles % 256 == 0 && kNaOffSamples % 256 == 0, "scratch pieces are 256-byte aligned");
+
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[kNaBytes];
+
+namespace {
+// Device address of `scratch` on each GPU (the array's name is only a host-side handle: every GPU
+// holds its own copy at its own address, found once per device with hipGetSymbolAddress).
+constexpr int kMaxDevices = 64;
+std::mutex g_scratchLock;
+unsigned char* g_scratchPtr[kMaxDevices] = {};
+
+hipError_t scratchForDevice(int device, unsigned char** out) {
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> hold(g_scratchLock);
+    if (!g_scratchPtr[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));      // the current device's copy
+        if (e != hipSuccess) return e;
+        g_scratchPtr[device] = (unsigned char*)p;
+    }
+    *out = g_scratchPtr[device];
+    return hipSuccess;
+}
 }  // namespace
 
 struct rtamd_ctx {
     int device = 0;
+    unsigned char* naScratch = nullptr;   // this GPU's copy of `scratch`
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t evStart = nullptr, evStop = nullptr;
@@ -182,7 +225,7 @@ int rtamd_ctx_create(int device_ordinal, rtamd_ctx** out_ctx) {
     rtamd_ctx* c = new (std::nothrow) rtamd_ctx();
     if (!c) return fail(nullptr, RTAMD_ERR_OUT_OF_MEMORY, "host allocation failed");
     c->device = device_ordinal;
-    if ((e = hipSetDevice(device_ordinal)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking)) != hipSuccess ||
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess || (e = scratchForDevice(device_ordinal, &c->naScratch)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess ||
         (e = c->counters.alloc(1)) != hipSuccess || (e = c->rayCount.alloc(2)) != hipSuccess || (e = c->errorFlag.alloc(1)) != hipSuccess || (e = c->redoCount.alloc(1)) != hipSuccess) {
         int rc = failHip(nullptr, e, "context creation");
@@ -190,6 +233,7 @@ int rtamd_ctx_create(int device_ordinal, rtamd_ctx** out_ctx) {
         return rc;
     }
     c->stream = c->ownStream;
+    c->fast.hSuper.reserve((size_t)kNaMaxTiles);     // the tile list of a launch never grows the heap after this
     *out_ctx = c;
     return RTAMD_OK;
 }
@@ -342,8 +386,12 @@ int rtamd_accum_reset(rtamd_ctx* c) {
     return RTAMD_OK;
 }
 
-int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_params* ext, int32_t width,
-                 int32_t height, float* out_rgba, int32_t* out_prim_id) {
+}  // extern "C"
+
+// One render.  noAlloc: working memory comes from this GPU's `scratch` array instead of the
+// context's growable buffers, outputs must be device memory, and nothing is allocated or freed.
+static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_params* ext, int32_t width,
+                      int32_t height, float* out_rgba, int32_t* out_prim_id, const bool noAlloc) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (!frame) return fail(c, RTAMD_ERR_INVALID_ARG, "frame is NULL");
     if (width <= 0 || height <= 0 || (int64_t)width * height > (1ll << 30)) return fail(c, RTAMD_ERR_INVALID_ARG, "bad image size");
@@ -361,6 +409,23 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
     if (e.shard_count > 1 && (e.shard_rank < 0 || e.shard_rank >= e.shard_count)) return fail(c, RTAMD_ERR_INVALID_ARG, "shard_rank out of range");
     HIP_TRY(c, hipSetDevice(c->device));
     size_t npix = (size_t)width * height;
+    if (noAlloc) {
+        const int64_t tiles = (int64_t)((width + 31) / 32) * (int64_t)((height + 31) / 32);
+        if ((int64_t)npix > kNaMaxPixels || tiles > kNaMaxTiles)
+            return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_noalloc: frame larger than 3840x2160 pixels (or more than 8192 tiles of 32x32)");
+        if (e.mode == RTAMD_MODE_PT && e.spp > kNaSampleCap) return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_noalloc: spp above 262144");
+        if ((out_rgba && !isDevicePointer(out_rgba)) || (out_prim_id && !isDevicePointer(out_prim_id)) || (e.out_t && !isDevicePointer(e.out_t)))
+            return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_noalloc: outputs must be device memory (a host buffer needs a staging allocation)");
+        if ((e.flags & RTAMD_FLAG_ACCUMULATE) && e.mode == RTAMD_MODE_PT && (c->accumW != width || c->accumH != height || !c->accum.p))
+            return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_noalloc: no running sum of this size yet (the first accumulating frame must go through rtamd_render)");
+    }
+    // working memory of this call
+    unsigned char* const na = c->naScratch;
+    rt::DevCounters* const dCounters = noAlloc ? (rt::DevCounters*)(na + kNaOffCounters) : c->counters.p;
+    unsigned long long* const dRayCount = noAlloc ? (unsigned long long*)(na + kNaOffRayCount) : c->rayCount.p;
+    int32_t* const dErrorFlag = noAlloc ? (int32_t*)(na + kNaOffErrorFlag) : c->errorFlag.p;
+    int32_t* const dRedoCount = noAlloc ? (int32_t*)(na + kNaOffRedoCount) : c->redoCount.p;
+    const rt::LaunchScratch lent = {(int32_t*)(na + kNaOffSuperTiles), kNaMaxTiles};
 
     rt::RenderArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -409,9 +474,9 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
         }
         a.accum = c->accum.p;
     }
-    a.counters = wantCounters ? c->counters.p : nullptr;
-    a.rayCount = c->rayCount.p;
-    a.errorFlag = c->errorFlag.p;
+    a.counters = wantCounters ? dCounters : nullptr;
+    a.rayCount = dRayCount;
+    a.errorFlag = dErrorFlag;
 
     rt::Sky sky;
     sky.texels = c->sky.p; sky.w = c->skyW; sky.h = c->skyH;
@@ -423,14 +488,21 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
     float ms = 0.f, handoverMs = 0.f;
     bool usedPool = false;
     const size_t maskWords = (npix + 31) / 32;
-    HIP_TRY(c, c->redoMask.alloc(maskWords));
-    HIP_TRY(c, c->redoList.alloc(npix));
-    HIP_TRY(c, hipMemsetAsync(c->redoMask.p, 0, maskWords * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->redoCount.p, 0, sizeof(int32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(rt::DevCounters), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->rayCount.p, 0, 2 * sizeof(unsigned long long), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->errorFlag.p, 0, sizeof(int32_t), c->stream));
-    a.redoMask = c->redoMask.p; a.redoList = c->redoList.p; a.redoCount = c->redoCount.p; a.redoCap = (int32_t)npix;
+    if (noAlloc) {
+        // the array keeps the last call's contents: everything that must start at zero is cleared here
+        a.redoMask = (uint32_t*)(na + kNaOffRedoMask); a.redoList = (int32_t*)(na + kNaOffRedoList);
+        a.redoCap = (int32_t)npix < kNaRedoCap ? (int32_t)npix : kNaRedoCap;
+    } else {
+        HIP_TRY(c, c->redoMask.alloc(maskWords));
+        HIP_TRY(c, c->redoList.alloc(npix));
+        a.redoMask = c->redoMask.p; a.redoList = c->redoList.p; a.redoCap = (int32_t)npix;
+    }
+    a.redoCount = dRedoCount;
+    HIP_TRY(c, hipMemsetAsync(a.redoMask, 0, maskWords * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(dRedoCount, 0, sizeof(int32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(dCounters, 0, sizeof(rt::DevCounters), c->stream));
+    HIP_TRY(c, hipMemsetAsync(dRayCount, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(dErrorFlag, 0, sizeof(int32_t), c->stream));
     rt::RefScene rsc;
     rsc.tlas = c->tlas.p; rsc.blasOffsets = c->blasOffsets.p; rsc.blas = c->blas.p; rsc.vtxOffsets = c->vtxOffsets.p;
     rsc.verts = c->verts.p; rsc.triOffsets = c->triOffsets.p; rsc.tris = c->tris.p; rsc.objects = c->objects.p;
@@ -440,37 +512,50 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
             dim3 grid((width + 7) / 8, (height + 7) / 8);
             hipLaunchKernelGGL(rt::kFaithful, grid, dim3(64), 0, c->stream, rsc, sky, a, (const int32_t*)nullptr, 0, (float4*)nullptr, 0);
         } else {
-            usedPool = a.mode == RTAMD_MODE_PT && rt::fastLaunchConfig().pool;
-            hipError_t le = usedPool ? rt::launchPool(c->fast, c->pool, sky, a, c->stream) : rt::launchFast(c->fast, sky, a, c->stream);
+            // (the path pool needs record and sample buffers sized to the frame: without allocations PT mode
+            // runs one path per lane, which gives the same image bit for bit)
+            usedPool = a.mode == RTAMD_MODE_PT && rt::fastLaunchConfig().pool && !noAlloc;
+            hipError_t le = usedPool ? rt::launchPool(c->fast, c->pool, sky, a, c->stream)
+                                     : rt::launchFast(c->fast, sky, a, c->stream, noAlloc ? &lent : nullptr);
             if (le != hipSuccess) return failHip(c, le, "production kernel launch");
         }
         HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&redo, c->redoCount.p, sizeof(redo), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&redo, dRedoCount, sizeof(redo), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipEventElapsedTime(&ms, c->evStart, c->evStop));
     c->lastTraceMs = usedPool ? c->pool.tracedMs() : ms;
     if (redo > 0) {
         // pixels the production kernel handed over (a ray with a zero direction component, or
         // a stack deeper than its LDS stack): the reference-order kernel renders exactly those
-        if (redo > (int32_t)npix) redo = (int32_t)npix;
+        if (redo > a.redoCap) redo = a.redoCap;       // (more than the list holds: the error flag says so below)
         float ms2 = 0.f;
         HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
         if (a.mode == RTAMD_MODE_PT) {
-            // one thread per (pixel, sample), then an in-order sum per pixel
-            const size_t n = (size_t)redo * (size_t)a.spp;
-            HIP_TRY(c, c->redoSamples.alloc(n));
-            const int spread = listSpreadFor(n);
-            hipLaunchKernelGGL(rt::kFaithful, dim3((unsigned)(((n << spread) + 63) / 64)), dim3(64), 0, c->stream, rsc, sky, a,
-                               (const int32_t*)c->redoList.p, redo, c->redoSamples.p, spread);
-            HIP_TRY(c, hipGetLastError());
-            hipLaunchKernelGGL(rt::kSumListedSamples, dim3((redo + 63) / 64), dim3(64), 0, c->stream, a,
-                               (const int32_t*)c->redoList.p, redo, (const float4*)c->redoSamples.p);
+            // one thread per (pixel, sample), then an in-order sum per pixel; in pieces of the list
+            // when the sample buffer is the fixed one
+            float4* samples = (float4*)(na + kNaOffSamples);
+            int32_t piece = redo;
+            if (noAlloc) piece = kNaSampleCap / a.spp;
+            else {
+                HIP_TRY(c, c->redoSamples.alloc((size_t)redo * (size_t)a.spp));
+                samples = c->redoSamples.p;
+            }
+            for (int32_t at = 0; at < redo; at += piece) {
+                const int32_t cnt = redo - at < piece ? redo - at : piece;
+                const size_t n = (size_t)cnt * (size_t)a.spp;
+                const int spread = listSpreadFor(n);
+                hipLaunchKernelGGL(rt::kFaithful, dim3((unsigned)(((n << spread) + 63) / 64)), dim3(64), 0, c->stream, rsc, sky, a,
+                                   (const int32_t*)a.redoList + at, cnt, samples, spread);
+                HIP_TRY(c, hipGetLastError());
+                hipLaunchKernelGGL(rt::kSumListedSamples, dim3((cnt + 63) / 64), dim3(64), 0, c->stream, a,
+                                   (const int32_t*)a.redoList + at, cnt, (const float4*)samples);
+            }
         } else {
             const int spread = listSpreadFor((size_t)redo);
             hipLaunchKernelGGL(rt::kFaithful, dim3((unsigned)((((size_t)redo << spread) + 63) / 64)), dim3(64), 0, c->stream, rsc, sky, a,
-                               (const int32_t*)c->redoList.p, redo, (float4*)nullptr, spread);
+                               (const int32_t*)a.redoList, redo, (float4*)nullptr, spread);
         }
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
@@ -484,9 +569,9 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
     if (getenv("RTAMD_VERBOSE"))
         fprintf(stderr, "[rtamd] render %dx%d mode %d: %.3f ms, %d pixels handed to the reference-order kernel; nodes %zu (BLAS %zu), depth BLAS %d TLAS %d, instances %d\n",
                 width, height, a.mode, ms, redo, c->fast.hNodes.size(), c->fast.nBlasNodes, c->fast.maxDepth, c->fast.tlasDepth, c->fast.nInst);
-    HIP_TRY(c, hipMemcpyAsync(&hc, c->counters.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(hr, c->rayCount.p, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&herr, c->errorFlag.p, sizeof(herr), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&hc, dCounters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hr, dRayCount, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&herr, dErrorFlag, sizeof(herr), hipMemcpyDeviceToHost, c->stream));
     if (out_rgba && !rgbaDev) HIP_TRY(c, hipMemcpyAsync(out_rgba, c->outRgba.p, npix * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     if (out_prim_id && !idsDev) HIP_TRY(c, hipMemcpyAsync(out_prim_id, c->outIds.p, npix * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     if (e.out_t && !tDev) HIP_TRY(c, hipMemcpyAsync(e.out_t, c->outT.p, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -499,7 +584,21 @@ int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext
         oc->max_blas_stack = hc.maxBlasStack; oc->max_tlas_stack = hc.maxTlasStack; oc->reserved = hc.overflow;
     }
     if (herr & 1) return fail(c, RTAMD_ERR_STACK_OVERFLOW, "traversal stack overflow (scene deeper than the shader's stacks allow)");
+    if (herr & 4) return fail(c, RTAMD_ERR_OUT_OF_MEMORY, noAlloc ? "rtamd_render_noalloc: more than 65536 pixels needed the reference-order kernel; render this frame with rtamd_render"
+                                                                    : "hand-over list overflow");
     return RTAMD_OK;
+}
+
+extern "C" {
+
+int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_params* ext, int32_t width,
+                 int32_t height, float* out_rgba, int32_t* out_prim_id) {
+    return renderCore(c, frame, ext, width, height, out_rgba, out_prim_id, false);
+}
+
+int rtamd_render_noalloc(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_params* ext, int32_t width,
+                         int32_t height, float* out_rgba_device, int32_t* out_prim_id_device) {
+    return renderCore(c, frame, ext, width, height, out_rgba_device, out_prim_id_device, true);
 }
 
 int rtamd_last_trace_kernel_ms(const rtamd_ctx* c, float* ms) {
