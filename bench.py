@@ -2,11 +2,19 @@
 """Headline benchmark: path-traced Mrays/s on one node of MI355X GPUs.
 
 A step is one full render of the workload: every pixel, every sample, every bounce, scene
-and framebuffers resident in HBM.  At N=1 the workload is BASELINE.json configs[1]: the
-random-spheres scene (floor + 484 instances of one sphere BLAS) at 1920x1080, 64 spp,
-8 bounces.  With N GPUs (one process per GPU, launched by torch.distributed.run) each rank
-renders the same image with its own 64-sample range and the per-pixel sums are all-reduced
-with RCCL inside the timed region (weak scaling: per-GPU work is fixed).
+and framebuffers resident in HBM.
+
+  N = 1   BASELINE.json configs[2]: the triangle-mesh scene built from the reference's
+          Assets/Models (peter / bunny / cow subdivided to 1 051 936 triangles, each mesh its
+          own BLAS, plus the sub-scene's emissive walls) at 1920x1080, 256 spp, 8 bounces.
+          The random-spheres scene of configs[1] (1080p, 64 spp) is measured as well and
+          reported inside the same line ("other_workloads").
+  N > 1   BASELINE.json configs[3]: the same scene at 3840x2160, 1024 spp in total, STRONG
+          scaling by tile sharding (one process per GPU, launched by torch.distributed.run):
+          rank r renders the 32x32-pixel tiles t with t % N == r into a zeroed frame, and the
+          frames are all-reduced (SUM) with RCCL over xGMI inside the timed region; the
+          result is bit-identical to the one-GPU image.  (--sharding samples selects sample
+          sharding instead: every rank renders total_spp / N samples of every pixel.)
 
 Prints ONE JSON line on rank 0.
 """
@@ -22,7 +30,10 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
-FP32_PEAK_TFLOPS = 157.3       # vector FP32, spec (packed FMA)
+FP32_PEAK_TFLOPS = 157.3       # vector FP32, spec: 256 CUs x 128 lanes x 2 (FMA) x 2.4 GHz
+VALU_ISSUE_PEAK_GINST = 256 * 4 * 2.4 / 4.0   # wave instructions per ns: 1024 SIMDs, one wave64 instruction per 4 cycles at 2.4 GHz
+
+DEFAULT_SPP = {"mesh": 256, "spheres": 64, "instanced": 64, "few": 4}
 
 
 def build_workload(name, width, height, tree=0):
@@ -30,7 +41,9 @@ def build_workload(name, width, height, tree=0):
     if name == "spheres":
         return scenes.random_spheres(width, height, tree=tree), "random-spheres: floor + 484 instanced spheres (one 960-triangle BLAS)"
     if name == "mesh":
-        return scenes.mesh_scene(width, height, tree=tree), "three procedural ~1M-triangle meshes + 4 quads"
+        s = scenes.mesh_scene(width, height, tree=tree)
+        what = ("Assets/Models peter+bunny+cow subdivided 2/3/2x" if scenes.have_models() else "three procedural meshes")
+        return s, f"triangle-mesh scene: {what} = {len(s[0].triangles)} triangles in 3 BLAS + 4 quads"
     if name == "instanced":
         return scenes.instanced_scene(width, height), "1 250 instances of three ~40 k-triangle meshes (50 M instanced triangles) on a floor"
     if name == "few":
@@ -39,25 +52,112 @@ def build_workload(name, width, height, tree=0):
 
 
 def cpu_baseline(buf, frame, sky, width, height, spp, bounces, seed):
-    """Time the scalar CPU oracle on a bounded sample of the same workload."""
+    """Time the scalar CPU oracle on a bounded sample of the same workload (about 10-20 s)."""
     from oracle import oracle as O
     cores = min(os.cpu_count() or 1, 16)
-    # sample: the same camera, scene and resolution at half the sample count (about 10-20 s on 16 cores)
-    sw, sh, sspp = width, height, max(1, spp // 2)
+    sspp = max(1, min(8, spp // 8))
     t0 = time.time()
-    r = O.render(buf, frame, sw, sh, sky=sky, mode=1, spp=sspp, max_bounces=bounces, seed=seed, nthreads=cores,
+    r = O.render(buf, frame, width, height, sky=sky, mode=1, spp=sspp, max_bounces=bounces, seed=seed, nthreads=cores,
                  want_ids=False, want_t=False)
     dt = time.time() - t0
     c = r["counters"]
-    # and one core alone on 2 spp of the same frame (a few seconds)
+    # and one core alone on a quarter-size tile of one sample (a few seconds)
     t1 = time.time()
-    r1 = O.render(buf, frame, sw, sh, sky=sky, mode=1, spp=min(2, sspp), max_bounces=bounces, seed=seed, nthreads=1,
-                  want_ids=False, want_t=False)
+    r1 = O.render(buf, frame, width, height, sky=sky, mode=1, spp=1, max_bounces=bounces, seed=seed, nthreads=1,
+                  tile=(width // 4, height // 4, width // 2, height // 2), want_ids=False, want_t=False)
     dt1 = time.time() - t1
     return {"value": c["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{sw}x{sh}, {sspp} spp, {bounces} bounces of the same scene and camera ({c['rays']} ray segments, {dt:.1f} s)",
+            "sample": f"{width}x{height}, {sspp} spp, {bounces} bounces of the same scene and camera ({c['rays']} ray segments, {dt:.1f} s)",
             "single_core_value": r1["counters"]["rays"] / dt1 / 1e6,
             "nodes_per_ray": c["nodes"] / max(1, c["rays"]), "tris_per_ray": c["tris"] / max(1, c["rays"])}
+
+
+def load_json(name):
+    p = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(p))
+    except Exception:
+        return None
+
+
+def roofline_for(rt, frame, W, Hh, out, args, workload, spp, kernel_ms_avg, sum_ms_avg, handover_ms_avg, last, kernel_name):
+    """Roofline object of one workload: algorithmic work (counted in the reference's traversal
+    order by the reference-order kernel) over the live duration of the dominant kernel, against
+    the ceiling that binds it, plus the other ceilings."""
+    from raytracing_amd import types as T
+    # counters depend on the sample count only through the number of paths: count 8 spp and scale
+    cspp = min(spp, 8)
+    c = rt.Execute(frame, W, Hh, out_rgba=out, counters=True, mode=T.MODE_PT, spp=cspp, max_bounces=args.bounces,
+                   seed=args.seed, sample_offset=0)["counters"]
+    per_ray = {k: c[k] / max(1, c["rays"]) for k in ("nodes", "tris", "instances", "hits")}
+    rays = last["rays"]                              # ray segments of one timed step on this rank
+    alg_bytes = rays * (116 * per_ray["nodes"] + 48 * per_ray["tris"] + 180 * per_ray["instances"] + 36 * per_ray["hits"])
+    alg_flops = rays * (100 * per_ray["nodes"] + 56 * per_ray["tris"] + 30 * per_ray["instances"])
+    secs = kernel_ms_avg * 1e-3
+    tflops = alg_flops / secs / 1e12
+    # offline evidence of the same step: rocprofv3 --pmc passes (tools/gpu_pmc.sh, tools/summarise_pmc.py)
+    # and the streaming ceilings of the cache levels (tools/l2_stream.hip)
+    pmc = None
+    rec = load_json("pmc_step.json")
+    if rec:
+        for r in rec.get("workloads", []):
+            if r.get("workload") == workload and r.get("spp") == spp and r.get("width") == W and r.get("height") == Hh:
+                pmc = r
+    ceil = load_json("r02_stream_ceilings.json")
+    ceilings = {"fp32_valu": {"achieved": tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_PEAK_TFLOPS,
+                              "what": "algorithmic flops (100/node + 56/triangle + 30/instance, reference-order counts) / kernel time"}}
+    traffic = None
+    if pmc:
+        traffic = pmc.get("hbm_bytes_per_step")
+        if traffic:
+            gbs = traffic / secs / 1e9
+            ceilings["hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                               "what": "fabric bytes of the step (PMC FETCH_SIZE x2 + WRITE_SIZE) / kernel time"}
+        if pmc.get("valu_wave_insts_per_step"):
+            gi = pmc["valu_wave_insts_per_step"] / secs / 1e9
+            ceilings["valu_issue"] = {"achieved": gi, "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave-instructions/s",
+                                      "frac": gi / VALU_ISSUE_PEAK_GINST, "lane_utilisation": pmc.get("valu_lane_utilisation"),
+                                      "what": "VALU wave instructions of the step (PMC SQ_INSTS_VALU) / kernel time against 1024 SIMDs x 1 per 4 cycles"}
+        if pmc.get("l2_read_bytes_per_step") and ceil:
+            level = "l2_0.2MB" if workload == "spheres" else "mall_84MB"
+            peak = ceil.get(level, {}).get("gather_node_GBps")
+            if peak:
+                gbs = pmc["l2_read_bytes_per_step"] / secs / 1e9
+                ceilings["l2_gather"] = {"achieved": gbs, "peak": peak, "unit": "GB/s", "frac": gbs / peak,
+                                         "write_requests_per_s": pmc.get("l2_write_requests_per_step", 0.0) / secs,
+                                         "what": f"L1->L2 read bytes of the step (PMC TCP_TCC_READ_REQ x 128 B) / kernel time against the measured rate of "
+                                                 f"per-lane 128-byte line gathers from a {level.split('_')[1]} working set (tools/l2_stream.hip)"}
+    # the ceiling that binds is the one with the largest fraction; FP32 VALU is what the contract prices
+    binding = max(ceilings.items(), key=lambda kv: kv[1]["frac"])[0]
+    v = ceilings["fp32_valu"]
+    return {"bound": "valu", "achieved": v["achieved"], "peak": v["peak"], "unit": v["unit"], "frac": v["frac"], "traffic": traffic,
+            "kernel": kernel_name, "kernel_ms": kernel_ms_avg, "sample_sum_ms": sum_ms_avg,
+            "handover_ms": handover_ms_avg, "handover_pixels": last["handover_pixels"],
+            "binding_ceiling": binding, "ceilings": ceilings,
+            "algorithmic_flops_per_step": alg_flops, "algorithmic_bytes_per_step": alg_bytes,
+            "throughput_equivalent_GBps": alg_bytes / secs / 1e9,
+            "bytes_per_ray": alg_bytes / max(1, rays), "flops_per_ray": alg_flops / max(1, rays),
+            "nodes_per_ray": per_ray["nodes"], "tris_per_ray": per_ray["tris"], "instances_per_ray": per_ray["instances"],
+            "counted_on": f"{cspp} spp of the same frame, scaled by ray segments",
+            "pmc_offline": {k: pmc[k] for k in ("simd_valu_issue_frac", "valu_lane_utilisation", "l2_hit_rate", "l1_accesses_per_cu_cycle",
+                                                "wave_cycles_waiting_frac", "salu_per_valu", "source") if pmc and k in pmc} or None}
+
+
+def timed_steps(step, steps, warmup, sync, barrier):
+    for _ in range(warmup):
+        step()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    acc = {"rays": 0, "kernel_ms": 0.0, "handover_ms": 0.0, "trace_ms": 0.0}
+    r = None
+    for _ in range(steps):
+        r = step()
+        for k in acc:
+            acc[k] += r[k]
+    sync()
+    barrier()
+    return time.perf_counter() - t0, acc, r
 
 
 def main():
@@ -65,15 +165,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="spheres")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--workload", default="mesh")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None, help="samples per pixel in total (default: 256 on one GPU, 1024 on several)")
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--tree", type=int, default=0, help="BLAS builder of the synthetic scene: 0 = reference median split, 1 = SAH")
+    ap.add_argument("--sharding", default="tiles", choices=["tiles", "samples"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the random-spheres measurement inside the one-GPU line")
     args = ap.parse_args()
 
     import torch
@@ -100,8 +202,14 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    (buf, frame, sky), desc = build_workload(args.workload, args.width, args.height, args.tree)
-    W, Hh = args.width, args.height
+    multi = world > 1
+    W = args.width or (3840 if multi and args.workload == "mesh" else 1920)
+    Hh = args.height or (2160 if multi and args.workload == "mesh" else 1080)
+    spp = args.spp or (1024 if multi and args.workload == "mesh" else DEFAULT_SPP.get(args.workload, 64))
+    if multi and args.sharding == "samples" and spp % world:
+        raise SystemExit("--spp must be a multiple of the GPU count with --sharding samples")
+
+    (buf, frame, sky), desc = build_workload(args.workload, W, Hh, args.tree)
     rt = backend.RayTracingPass(dev_index)
     # kernels, the RCCL all-reduce and the normalisation all run on torch's current stream
     rt.SetStream(torch.cuda.current_stream().cuda_stream)
@@ -111,35 +219,27 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        # each rank renders its own sample range; sums are combined below
-        flags = T.FLAG_OUTPUT_SUM if world > 1 else 0
-        r = rt.Execute(frame, W, Hh, out_rgba=out, mode=T.MODE_PT, spp=args.spp, max_bounces=args.bounces,
-                       seed=args.seed, sample_offset=rank * args.spp, flags=flags)
-        if world > 1:
-            D.combine_samples(out)     # RCCL all-reduce (SUM) of the sum buffer over xGMI, then / sample count
+        if not multi:
+            return rt.Execute(frame, W, Hh, out_rgba=out, mode=T.MODE_PT, spp=spp, max_bounces=args.bounces, seed=args.seed)
+        if args.sharding == "tiles":
+            out.zero_()                                         # pixels of other ranks' tiles must be 0 for the SUM
+            r = rt.Execute(frame, W, Hh, out_rgba=out, mode=T.MODE_PT, spp=spp, max_bounces=args.bounces, seed=args.seed,
+                           **D.tile_shard_kwargs(rank, world))
+            D.combine_tiles([out])                              # RCCL all-reduce (SUM) over xGMI: every rank ends with the whole frame
+            return r
+        per = spp // world
+        r = rt.Execute(frame, W, Hh, out_rgba=out, mode=T.MODE_PT, spp=per, max_bounces=args.bounces, seed=args.seed,
+                       sample_offset=rank * per, flags=T.FLAG_OUTPUT_SUM)
+        D.combine_samples(out)                                  # RCCL all-reduce (SUM) of the sum buffer, then / sample count
         return r
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rays = 0
-    kernel_ms = 0.0
-    handover_ms = 0.0
-    trace_ms = 0.0
-    for _ in range(args.steps):
-        r = step()
-        rays += r["rays"]
-        kernel_ms += r["kernel_ms"]
-        handover_ms += r["handover_ms"]
-        trace_ms += r["trace_ms"]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
+    def barrier():
+        if multi:
+            dist.barrier()
+
+    elapsed, acc, last = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, barrier)
+    rays = acc["rays"]
+    if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -147,65 +247,61 @@ def main():
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         rays = int(rr.item())
     value = rays / elapsed / 1e6
-    rays_per_launch_local = r["rays"]
-    # the path-tracing kernel alone (what rocprofv3 lists as rt::kPool), the summation of the samples
-    # behind it, and the hand-over pass
-    handover_ms_avg = handover_ms / max(1, args.steps)
-    kernel_ms_avg = trace_ms / max(1, args.steps)
-    sum_ms_avg = kernel_ms / max(1, args.steps) - handover_ms_avg - kernel_ms_avg
+    n = max(1, args.steps)
+    # the path-tracing kernel alone (what rocprofv3 lists as rt::kPool: all its launches of one step), the
+    # summation of the samples behind it, and the hand-over pass
+    handover_ms_avg = acc["handover_ms"] / n
+    kernel_ms_avg = acc["trace_ms"] / n
+    sum_ms_avg = acc["kernel_ms"] / n - handover_ms_avg - kernel_ms_avg
     kernel_name = "rt::kFast<PT>" if os.environ.get("RTAMD_PIPELINE") == "persistent" or os.environ.get("RTAMD_STATS") else "rt::kPool"
 
     result = None
     if rank == 0:
-        # algorithmic work of ONE launch on this rank, counted in the reference's traversal order
         roofline = None
         if not args.no_counters:
-            c = rt.Execute(frame, W, Hh, out_rgba=out, counters=True, mode=T.MODE_PT, spp=args.spp, max_bounces=args.bounces,
-                           seed=args.seed, sample_offset=0)["counters"]
-            alg_bytes = 116 * c["nodes"] + 48 * c["tris"] + 180 * c["instances"] + 36 * c["hits"]
-            alg_flops = 100 * c["nodes"] + 56 * c["tris"] + 30 * c["instances"]
-            achieved = alg_bytes / (kernel_ms_avg * 1e-3) / 1e9
-            # counters of the same launch, collected offline with rocprofv3 --pmc (tools/gpu_pmc.sh)
-            traffic, pmc_extra = None, None
-            pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    rec = json.load(open(pmc))
-                    if rec.get("workload") == args.workload and rec.get("spp") == args.spp and rec.get("width") == W:
-                        traffic = rec.get("hbm_bytes_per_launch")
-                        pmc_extra = {k: rec[k] for k in ("simd_valu_issue_frac", "valu_lane_utilisation", "l2_hit_rate",
-                                                         "l1_accesses_per_cu_cycle", "wave_cycles_waiting_frac") if k in rec}
-                except Exception:
-                    traffic, pmc_extra = None, None
-            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                        "kernel": kernel_name, "kernel_ms": kernel_ms_avg, "sample_sum_ms": sum_ms_avg,
-                        "handover_ms": handover_ms_avg, "handover_pixels": r["handover_pixels"],
-                        "algorithmic_bytes_per_launch": alg_bytes,
-                        "bytes_per_ray": alg_bytes / max(1, c["rays"]),
-                        "nodes_per_ray": c["nodes"] / max(1, c["rays"]), "tris_per_ray": c["tris"] / max(1, c["rays"]),
-                        "instances_per_ray": c["instances"] / max(1, c["rays"]),
-                        "valu_tflops_algorithmic": alg_flops / (kernel_ms_avg * 1e-3) / 1e12,
-                        "valu_frac_of_fp32_peak": alg_flops / (kernel_ms_avg * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                        "kernel_mrays_per_s": rays_per_launch_local / (kernel_ms_avg * 1e-3) / 1e6,
-                        "pmc_offline": pmc_extra}
+            roofline = roofline_for(rt, frame, W, Hh, out, args, args.workload, spp, kernel_ms_avg, sum_ms_avg, handover_ms_avg, last, kernel_name)
+        others = None
+        if not multi and not args.no_secondary and args.workload == "mesh":
+            # configs[1], the random-spheres scene at 1080p / 64 spp, on the same context
+            (buf2, frame2, sky2), desc2 = build_workload("spheres", 1920, 1080, args.tree)
+            rt.SetScene(buf2)
+            rt.SetSkyBox(sky2)
+            out2 = torch.zeros((1080, 1920, 4), dtype=torch.float32, device=dev)
+            spp2 = DEFAULT_SPP["spheres"]
+
+            def step2():
+                return rt.Execute(frame2, 1920, 1080, out_rgba=out2, mode=T.MODE_PT, spp=spp2, max_bounces=args.bounces, seed=args.seed)
+            e2, a2, l2 = timed_steps(step2, max(2, args.steps), 1, torch.cuda.synchronize, lambda: None)
+            n2 = max(2, args.steps)
+            others = {"spheres": {"workload": f"{desc2}, 1920x1080, {spp2} spp, {args.bounces} bounces", "value": a2["rays"] / e2 / 1e6,
+                                  "unit": "Mrays/s", "ms_per_step": e2 / n2 * 1e3, "steps": n2,
+                                  "roofline": None if args.no_counters else roofline_for(
+                                      rt, frame2, 1920, 1080, out2, args, "spheres", spp2, a2["trace_ms"] / n2,
+                                      a2["kernel_ms"] / n2 - a2["handover_ms"] / n2 - a2["trace_ms"] / n2, a2["handover_ms"] / n2, l2, kernel_name)}}
         base = None
-        if not args.no_cpu_baseline and world == 1:
-            base = cpu_baseline(buf, frame, sky, W, Hh, args.spp, args.bounces, args.seed)
+        if not args.no_cpu_baseline and not multi:
+            base = cpu_baseline(buf, frame, sky, W, Hh, spp, args.bounces, args.seed)
+        if multi:
+            par = (f"tile-sharded x{world} (32x32 tiles, t % {world}), RCCL all-reduce of the frame" if args.sharding == "tiles"
+                   else f"sample-sharded x{world}, RCCL all-reduce of the sum buffer")
+        else:
+            par = "single GPU"
         result = {
             "metric": "Mrays/s (path-traced, incl. bounces)", "value": value, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / n * 1e3, "higher_is_better": True, "scaling": "strong" if multi else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{desc}, {W}x{Hh}, {args.spp} spp/GPU, {args.bounces} bounces",
-                       "resolution": [W, Hh], "spp_per_gpu": args.spp, "max_bounces": args.bounces,
-                       "parallelism": f"sample-sharded x{world}, RCCL all-reduce of the sum buffer" if world > 1 else "single GPU",
-                       "samples_per_s": W * Hh * args.spp * world / (elapsed / max(1, args.steps))},
+            "config": {"workload": f"{desc}, {W}x{Hh}, {spp} spp in total, {args.bounces} bounces",
+                       "resolution": [W, Hh], "spp_total": spp, "max_bounces": args.bounces, "parallelism": par,
+                       "ray_segments_per_step": rays // n,
+                       "samples_per_s": W * Hh * spp / (elapsed / n)},
             "roofline": roofline, "cpu_baseline": base,
         }
+        if others:
+            result["other_workloads"] = others
         print(json.dumps(result), flush=True)
     rt.Dispose()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return result

@@ -206,10 +206,49 @@ class SceneBuffers:
     def save(self, path):
         np.savez_compressed(path, **{f: getattr(self, f) for f in self.FIELDS})
 
+    def _as_host(self):
+        hb = T.HostBuffers()
+        hb.tlas, hb.n_tlas_nodes = self.tlas.ctypes.data, len(self.tlas)
+        hb.blas_offsets, hb.blas, hb.n_blas_nodes = self.blas_offsets.ctypes.data, self.blas.ctypes.data, len(self.blas)
+        hb.vertices_offsets, hb.vertices, hb.n_vertices = self.vertices_offsets.ctypes.data, self.vertices.ctypes.data, len(self.vertices)
+        hb.triangles_offsets, hb.triangles, hb.n_triangles = self.triangles_offsets.ctypes.data, self.triangles.ctypes.data, len(self.triangles)
+        hb.n_blas, hb.objects, hb.n_objects = self.n_blas, self.objects.ctypes.data, len(self.objects)
+        hb.tlas_branch_count = self.tlas_branch_count
+        return hb
+
+    def save_file(self, path):
+        """Flattened-scene file (rtamd_host_scene_save): the eight arrays behind a small header."""
+        hb = self._as_host()
+        _check(lib().rtamd_host_scene_save(C.byref(hb), os.fsencode(path)), "scene_save")
+
+    @staticmethod
+    def load_file(path):
+        """Read a flattened-scene file back (rtamd_host_scene_load)."""
+        s = lib().rtamd_host_scene_create()
+        try:
+            _check(lib().rtamd_host_scene_load(s, os.fsencode(path)), "scene_load")
+            hb = T.HostBuffers()
+            _check(lib().rtamd_host_scene_buffers(s, C.byref(hb)), "buffers")
+            return _buffers_from_host(hb)
+        finally:
+            lib().rtamd_host_scene_destroy(s)
+
     @staticmethod
     def load(path):
         z = np.load(path, allow_pickle=False)
         return SceneBuffers(*[z[f] for f in SceneBuffers.FIELDS])
+
+
+def _buffers_from_host(hb):
+    """Numpy copies of the arrays a rtamd_host_buffers record points at."""
+    def arr(ptr, n, dt):
+        buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dt, count=n).copy()
+    return SceneBuffers(arr(hb.tlas, hb.n_tlas_nodes, T.NODE), arr(hb.blas_offsets, hb.n_blas, np.int32),
+                        arr(hb.blas, hb.n_blas_nodes, T.NODE), arr(hb.vertices_offsets, hb.n_blas, np.int32),
+                        arr(hb.vertices, hb.n_vertices, T.VERTEX), arr(hb.triangles_offsets, hb.n_blas, np.int32),
+                        arr(hb.triangles, hb.n_triangles, T.INT3), arr(hb.objects, hb.n_objects, T.OBJECT),
+                        hb.tlas_branch_count)
 
 
 class BuildAccelerateStructureSystem:
@@ -259,15 +298,7 @@ class BuildAccelerateStructureSystem:
         _check(lib().rtamd_host_scene_update(self._s), "OnUpdate")
         hb = T.HostBuffers()
         _check(lib().rtamd_host_scene_buffers(self._s, C.byref(hb)), "buffers")
-
-        def arr(ptr, n, dt):
-            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
-            return np.frombuffer(buf, dtype=dt, count=n).copy()
-        return SceneBuffers(arr(hb.tlas, hb.n_tlas_nodes, T.NODE), arr(hb.blas_offsets, hb.n_blas, np.int32),
-                            arr(hb.blas, hb.n_blas_nodes, T.NODE), arr(hb.vertices_offsets, hb.n_blas, np.int32),
-                            arr(hb.vertices, hb.n_vertices, T.VERTEX), arr(hb.triangles_offsets, hb.n_blas, np.int32),
-                            arr(hb.triangles, hb.n_triangles, T.INT3), arr(hb.objects, hb.n_objects, T.OBJECT),
-                            hb.tlas_branch_count)
+        return _buffers_from_host(hb)
 
 
 def trs(t=(0, 0, 0), q=(0, 0, 0, 1), s=(1, 1, 1)):

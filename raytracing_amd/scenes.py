@@ -117,19 +117,38 @@ def _bumpy_sphere(segments, rings, seed):
     return H.Mesh(p.astype(np.float32), vn.astype(np.float32), tri)
 
 
+MODELS_NPZ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "reference_models.npz")
+
+
+def load_model(name, models_dir=None):
+    """One of the reference's meshes (peter, bunny, cow: Assets/Models/*.dae) as the COLLADA loader
+    reads it: from the .dae when `models_dir` holds it, otherwise from the committed arrays the
+    loader produced (tests/golden/reference_models.npz, written by tests/golden/make_golden.py)."""
+    if models_dir and os.path.exists(os.path.join(models_dir, name + ".dae")):
+        return H.Mesh.load_dae(os.path.join(models_dir, name + ".dae"))
+    z = np.load(MODELS_NPZ, allow_pickle=False)
+    return H.Mesh(z[name + "_positions"], z[name + "_normals"], z[name + "_indices"])
+
+
+def have_models(models_dir=None):
+    return bool(models_dir and os.path.exists(os.path.join(models_dir, "peter.dae"))) or os.path.exists(MODELS_NPZ)
+
+
 def mesh_scene(width=1920, height=1080, models_dir=None, target_tris=1_000_000,
-               tree=H.BuildAccelerateStructureSystem.MEDIAN):
+               tree=H.BuildAccelerateStructureSystem.MEDIAN, procedural=False):
     """Config 3: three unique large meshes (~1 M triangles in total) + three emissive walls.
 
-    With `models_dir` (the reference's Assets/Models) the meshes are peter / bunny / cow
-    subdivided 2 / 3 / 2 times = 1 051 936 triangles; without it, three procedural
-    displaced spheres with the same triangle budget split (61 % / 30 % / 9 %)."""
+    The meshes are the reference's peter / bunny / cow (Assets/Models/peter.dae:56,78,
+    bunny.dae:42,64, cow.dae:42,64) subdivided 2 / 3 / 2 times = 1 051 936 triangles (1 / 2 / 1
+    rounds = 165 256 and no subdivision = 50 842 for smaller targets); with `procedural` (or
+    when neither the .dae files nor their committed arrays are there), three displaced spheres
+    with the same triangle budget split (61 % / 30 % / 9 %)."""
     meshes = []
-    if models_dir and os.path.exists(os.path.join(models_dir, "peter.dae")):
+    if not procedural and have_models(models_dir):
         scale = target_tris / 1_051_936.0
         rounds = (2, 3, 2) if scale > 0.5 else ((1, 2, 1) if scale > 0.1 else (0, 0, 0))
         for name, r in zip(("peter", "bunny", "cow"), rounds):
-            meshes.append(H.Mesh.load_dae(os.path.join(models_dir, name + ".dae")).subdivide(r))
+            meshes.append(load_model(name, models_dir).subdivide(r))
     else:
         for frac, seed in ((0.61, 11), (0.30, 12), (0.09, 13)):
             tris = max(64, int(target_tris * frac))
@@ -160,12 +179,12 @@ def mesh_scene(width=1920, height=1080, models_dir=None, target_tris=1_000_000,
     return buf, frame, procedural_sky()
 
 
-def reference_scene(models_dir, width=1920, height=1080):
+def reference_scene(models_dir=None, width=1920, height=1080):
     """The reference's own sample: `peter` + three emissive walls with the sample camera
     (Assets/Scenes/SubScenes/RayTracingSubScene.unity:151,219-221,305-307,416-418,567-569;
-    Assets/Scenes/SampleScene.unity:638-640,666-667).  Needs the reference's peter.dae."""
+    Assets/Scenes/SampleScene.unity:638-640,666-667)."""
     sys = H.BuildAccelerateStructureSystem()
-    peter = sys.BakeBLAS(H.Mesh.load_dae(os.path.join(models_dir, "peter.dae")))
+    peter = sys.BakeBLAS(load_model("peter", models_dir))
     quad = sys.BakeBLAS(H.Mesh.quad())
     parent = np.array([20.050472, -2.750208, 25.932217])
     face = dict(albedo=(1, 1, 1), specular=(0.2, 0.2, 0.2))

@@ -34,7 +34,7 @@ def scene_random_small():
 @pytest.fixture(scope="session")
 def scene_mesh_small():
     from raytracing_amd import scenes
-    return scenes.mesh_scene(96, 54, target_tris=20000)
+    return scenes.mesh_scene(96, 54, target_tris=20000, procedural=True)
 
 
 @pytest.fixture(scope="session")

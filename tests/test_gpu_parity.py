@@ -89,13 +89,16 @@ def test_many_instances_tlas_larger_than_the_lds_copy(gpu_pass, oracle):
 
 @pytest.mark.parametrize("workload", ["spheres", "mesh"])
 def test_full_size_production_kernel_equals_reference_order_kernel(gpu_pass, oracle, workload):
-    """Benchmark-size scenes at 1920x1080 (2 spp, so that the CPU oracle finishes in seconds): the
+    """Benchmark scenes at their full size — 485 instances; peter / bunny / cow subdivided to
+    1 051 936 triangles — at 1920x1080 (2 spp, so that the CPU oracle finishes in seconds): the
     production kernel (rebuilt trees, nearest-first, LDS copies), the reference-order kernel (the
     caller's trees, the shader's visiting order) and the oracle must agree on every pixel, bit
     for bit; and a render split in shards must equal the whole."""
     from raytracing_amd import scenes
     w, h = 1920, 1080
-    buf, frame, sky = scenes.random_spheres(w, h) if workload == "spheres" else scenes.mesh_scene(w, h, target_tris=200_000)
+    buf, frame, sky = scenes.random_spheres(w, h) if workload == "spheres" else scenes.mesh_scene(w, h)
+    if workload == "mesh":
+        assert len(buf.triangles) == 1_051_936 + 2 and buf.n_blas == 4
     gpu_pass.SetScene(buf)
     gpu_pass.SetSkyBox(sky)
     kw = dict(mode=T.MODE_PT, spp=2, max_bounces=8, seed=77)
@@ -263,17 +266,25 @@ def test_tlas_built_on_the_device_single_object(device_tlas, oracle):
     assert (o["ids"][..., 0] >= 0).any()
 
 
-def test_4k_frame_production_kernel_equals_reference_order_kernel(gpu_pass):
-    """3840x2160 (the multi-GPU configuration's frame): production and reference-order kernels agree
-    on every pixel, and four interleaved tile shards compose to the whole frame."""
+def test_4k_frame_production_kernel_equals_reference_order_kernel(gpu_pass, oracle):
+    """3840x2160 on the 1 051 936-triangle scene (the multi-GPU configuration's frame): production
+    and reference-order kernels agree on every pixel, a 960x540 rectangle of the frame equals the
+    CPU oracle's, and four interleaved tile shards compose to the whole frame."""
     from raytracing_amd import scenes
     w, h = 3840, 2160
-    buf, frame, sky = scenes.mesh_scene(w, h, target_tris=200_000)
+    buf, frame, sky = scenes.mesh_scene(w, h)
+    assert len(buf.triangles) == 1_051_936 + 2
     gpu_pass.SetScene(buf)
     gpu_pass.SetSkyBox(sky)
     kw = dict(mode=T.MODE_PT, spp=1, max_bounces=8, seed=4)
     fast = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, **kw)
     ref = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, flags=T.FLAG_REFERENCE_ORDER, **kw)
+    tile = (1500, 700, 960, 540)
+    o = oracle.render(buf, frame, w, h, sky=sky, mode=1, spp=1, max_bounces=8, seed=4, tile=tile, nthreads=16)
+    ys, xs = slice(tile[1], tile[1] + tile[3]), slice(tile[0], tile[0] + tile[2])
+    assert _same(fast["ids"][ys, xs], o["ids"][ys, xs]) and _same(fast["t"][ys, xs], o["t"][ys, xs])
+    assert _same(fast["rgba"][ys, xs], o["rgba"][ys, xs])
+    assert len(np.unique(o["ids"][ys, xs, 0])) >= 4
     assert _same(fast["ids"], ref["ids"]), _report("4k", fast, ref)
     assert _same(fast["t"], ref["t"])
     assert _same(fast["rgba"], ref["rgba"]), _report("4k", fast, ref)

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 cd /tmp
 run() {
   name=$1; shift
-  timeout -s KILL 240 rocprofv3 --pmc $@ --output-format csv -d "$OUT/$name" -o "$name" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-counters --steps 1 --warmup 0 $BENCH_ARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
+  timeout -s KILL 240 rocprofv3 --pmc $@ --output-format csv -d "$OUT/$name" -o "$name" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-counters --no-secondary --steps 1 --warmup 0 $BENCH_ARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
   python3 - "$OUT/$name" <<'PY'
 import sys, glob, csv, collections
 d = sys.argv[1]

@@ -8,6 +8,6 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o "$TAG" -- python3 "$ROOT/bench.py" --no-cpu-baseline "$@" > "$OUT/bench.log" 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o "$TAG" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-secondary "$@" > "$OUT/bench.log" 2>&1
 tail -2 "$OUT/bench.log"
 find "$OUT" -name "*kernel_stats.csv" | head -3 | while read f; do echo "== $f"; head -12 "$f"; done

@@ -46,5 +46,39 @@ def summarise(tag):
     return d
 
 
+def step_record(tag, workload, width, height, spp, source):
+    """The figures bench.py reads back (profiles/pmc_step.json) for one workload: per step of the bench,
+    i.e. all launches of the production kernel in one render."""
+    d = summarise(tag)
+    der = d["derived"]
+    rec = {"workload": workload, "width": width, "height": height, "spp": spp, "source": source}
+    if "hbm_bytes_per_launch_corrected" in der:
+        rec["hbm_bytes_per_step"] = der["hbm_bytes_per_launch_corrected"]
+    if "SQ_INSTS_VALU" in d:
+        rec["valu_wave_insts_per_step"] = d["SQ_INSTS_VALU"]
+        if d.get("SQ_INSTS_SALU"):
+            rec["salu_per_valu"] = d["SQ_INSTS_SALU"] / d["SQ_INSTS_VALU"]
+    if "TCP_TCC_READ_REQ_sum" in d:
+        # L1 -> L2 read requests are whole 128-byte lines on this part (a counter pass over tools/l2_stream,
+        # whose byte count is known, gives 128.0 bytes per request); write requests carry what one store
+        # instruction wrote to a line (16 bytes per lane here) and are listed as a count
+        rec["l2_read_bytes_per_step"] = 128.0 * d["TCP_TCC_READ_REQ_sum"]
+        rec["l2_write_requests_per_step"] = d.get("TCP_TCC_WRITE_REQ_sum", 0.0)
+    for k in ("simd_valu_issue_frac", "valu_lane_utilisation", "l2_hit_rate", "l1_accesses_per_cu_cycle", "wave_cycles_waiting_frac"):
+        if k in der:
+            rec[k] = der[k]
+    return rec
+
+
 if __name__ == "__main__":
-    print(json.dumps({t: summarise(t) for t in sys.argv[1:]}, indent=1))
+    if len(sys.argv) > 1 and sys.argv[1] == "--step":
+        # --step <out.json> <source note> tag:workload:width:height:spp ...
+        out, source = sys.argv[2], sys.argv[3]
+        recs = []
+        for spec in sys.argv[4:]:
+            tag, wl, w, h, spp = spec.split(":")
+            recs.append(step_record(tag, wl, int(w), int(h), int(spp), source))
+        json.dump({"workloads": recs}, open(out, "w"), indent=1)
+        print(json.dumps({"workloads": recs}, indent=1))
+    else:
+        print(json.dumps({t: summarise(t) for t in sys.argv[1:]}, indent=1))
