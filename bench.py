@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--tree", type=int, default=0, help="BLAS builder of the synthetic scene: 0 = reference median split, 1 = SAH")
     ap.add_argument("--sharding", default="tiles", choices=["tiles", "samples"])
+    ap.add_argument("--single-process", action="store_true",
+                    help="with --gpus N and no launcher: one process, one context over GPUs 0..N-1 (rtamd_ctx_create_multi), "
+                         "tile-sharded, frame gathered onto GPU 0 with RCCL inside the library")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-counters", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the random-spheres measurement inside the one-GPU line")
@@ -203,22 +206,33 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     multi = world > 1
-    W = args.width or (3840 if multi and args.workload == "mesh" else 1920)
-    Hh = args.height or (2160 if multi and args.workload == "mesh" else 1080)
-    spp = args.spp or (1024 if multi and args.workload == "mesh" else DEFAULT_SPP.get(args.workload, 64))
+    inproc = args.single_process and world == 1 and args.gpus > 1      # several GPUs inside one context
+    if inproc:
+        multi_shape = True
+    else:
+        multi_shape = multi
+    W = args.width or (3840 if multi_shape and args.workload == "mesh" else 1920)
+    Hh = args.height or (2160 if multi_shape and args.workload == "mesh" else 1080)
+    spp = args.spp or (1024 if multi_shape and args.workload == "mesh" else DEFAULT_SPP.get(args.workload, 64))
     if multi and args.sharding == "samples" and spp % world:
         raise SystemExit("--spp must be a multiple of the GPU count with --sharding samples")
 
     (buf, frame, sky), desc = build_workload(args.workload, W, Hh, args.tree)
-    rt = backend.RayTracingPass(dev_index)
-    # kernels, the RCCL all-reduce and the normalisation all run on torch's current stream
-    rt.SetStream(torch.cuda.current_stream().cuda_stream)
+    if inproc:
+        rt = backend.RayTracingPass(devices=list(range(args.gpus)))
+    else:
+        rt = backend.RayTracingPass(dev_index)
+        # kernels, the RCCL all-reduce and the normalisation all run on torch's current stream
+        rt.SetStream(torch.cuda.current_stream().cuda_stream)
     rt.SetScene(buf)
     rt.SetSkyBox(sky)
     out = torch.zeros((Hh, W, 4), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
     def step():
+        if inproc:
+            return rt.Execute(frame, W, Hh, out_rgba=out, mode=T.MODE_PT, spp=spp, max_bounces=args.bounces, seed=args.seed,
+                              flags=T.FLAG_SHARD_SAMPLES if args.sharding == "samples" else 0)
         if not multi:
             return rt.Execute(frame, W, Hh, out_rgba=out, mode=T.MODE_PT, spp=spp, max_bounces=args.bounces, seed=args.seed)
         if args.sharding == "tiles":
@@ -253,7 +267,7 @@ def main():
     handover_ms_avg = acc["handover_ms"] / n
     kernel_ms_avg = acc["trace_ms"] / n
     sum_ms_avg = acc["kernel_ms"] / n - handover_ms_avg - kernel_ms_avg
-    kernel_name = "rt::kFast<PT>" if os.environ.get("RTAMD_PIPELINE") == "persistent" or os.environ.get("RTAMD_STATS") else "rt::kPool"
+    kernel_name = "rt::kFast<PT>" if os.environ.get("RTAMD_PIPELINE") == "persistent" else "rt::kPool"
 
     result = None
     if rank == 0:
@@ -281,15 +295,19 @@ def main():
         base = None
         if not args.no_cpu_baseline and not multi:
             base = cpu_baseline(buf, frame, sky, W, Hh, spp, args.bounces, args.seed)
-        if multi:
-            par = (f"tile-sharded x{world} (32x32 tiles, t % {world}), RCCL all-reduce of the frame" if args.sharding == "tiles"
-                   else f"sample-sharded x{world}, RCCL all-reduce of the sum buffer")
+        if inproc:
+            mi = rt.MultiInfo()
+            par = (f"one process, one context over {mi['devices']} GPUs, {args.sharding}-sharded, exchange inside the library: "
+                   + (f"RCCL, {mi['rccl_ranks']} ranks" if mi["rccl_ranks"] else f"peer copies ({mi['note']})") + f", {mi['exchange_ms']:.3f} ms per frame")
+        elif multi:
+            par = (f"tile-sharded x{world} (32x32 tiles, t % {world}), RCCL all-reduce of the frame, {dist.get_world_size()} ranks" if args.sharding == "tiles"
+                   else f"sample-sharded x{world}, RCCL all-reduce of the sum buffer, {dist.get_world_size()} ranks")
         else:
             par = "single GPU"
         result = {
             "metric": "Mrays/s (path-traced, incl. bounces)", "value": value, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / n * 1e3, "higher_is_better": True, "scaling": "strong" if multi else "weak",
+            "n_gpus": args.gpus if inproc else world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / n * 1e3, "higher_is_better": True, "scaling": "strong" if (multi or inproc) else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{desc}, {W}x{Hh}, {spp} spp in total, {args.bounces} bounces",
                        "resolution": [W, Hh], "spp_total": spp, "max_bounces": args.bounces, "parallelism": par,

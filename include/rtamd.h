@@ -89,7 +89,8 @@ enum {
     RTAMD_FLAG_NO_JITTER       = 1 << 1, /* PT: use FrameCBuffer.PixelOffset instead of a random sub-pixel offset */
     RTAMD_FLAG_REFERENCE_ORDER = 1 << 2, /* traverse in the reference's exact node order on the reference's own node layout */
     RTAMD_FLAG_OUTPUT_SUM      = 1 << 3, /* PT: write the un-normalised sample sum (for cross-GPU sample sharding) */
-    RTAMD_FLAG_COUNTERS        = 1 << 4  /* also fill the work counters (forces REFERENCE_ORDER so the counts are the reference's) */
+    RTAMD_FLAG_COUNTERS        = 1 << 4, /* also fill the work counters (forces REFERENCE_ORDER so the counts are the reference's) */
+    RTAMD_FLAG_SHARD_SAMPLES   = 1 << 5  /* PT on a context over several GPUs: split the samples, not the tiles, over the GPUs */
 };
 
 /* Work counters, summed over every ray segment of one render call. */
@@ -137,6 +138,28 @@ typedef struct rtamd_ctx rtamd_ctx;
 /* Replaces the ComputeShader / ComputeBuffer ownership of RayTracingPass.Create
  * (RayTracingPass.cs:119-125) and BuildAccelerateStructureSystem.OnCreate (:35-39). */
 int rtamd_ctx_create(int device_ordinal, rtamd_ctx** out_ctx);
+
+/* One context over several GPUs of the node, in this one process (the reference is one Unity
+ * process on one GPU: RayTracingPass.cs:62-109 has nothing to replace here; this is what its
+ * dispatch needs when the image is partitioned).  Every other entry point takes the context as
+ * it takes an ordinary one: a scene upload replicates the scene on every device (one host
+ * thread each), rtamd_render splits the frame — by default the 32x32-pixel tiles t with
+ * t % n == d go to device d, with RTAMD_FLAG_SHARD_SAMPLES (PT) every device renders its share
+ * of the samples — and assembles it on device_ordinals[0]: the tiles are gathered
+ * (bit-identical to a one-GPU render), the sample sums reduced (equal up to fp32 summation
+ * order), with RCCL over xGMI (ncclSend/ncclRecv, ncclReduce; one communicator rank per
+ * device, ncclCommInitAll) or, when a device is listed twice or librccl cannot be loaded,
+ * with peer copies.  out_rgba / out_prim_id / ext->out_t may be host memory or device memory
+ * of any GPU.  Not available on such a context: rtamd_set_stream, rtamd_render_noalloc,
+ * ext->shard_count > 1, RTAMD_FLAG_ACCUMULATE together with RTAMD_FLAG_SHARD_SAMPLES. */
+int rtamd_ctx_create_multi(const int32_t* device_ordinals, int32_t n_devices, rtamd_ctx** out_ctx);
+
+/* Number of devices of the context (1 for an ordinary one), the rank count of the RCCL
+ * communicator that carries the exchange (0: peer copies), and the device time of the last
+ * frame's exchange step.  Any pointer may be NULL.  No counterpart in the reference. */
+int rtamd_multi_info(const rtamd_ctx* ctx, int32_t* n_devices, int32_t* rccl_ranks, float* last_exchange_ms);
+/* Why RCCL is not carrying the exchange, or "" when it is.  Never NULL. */
+const char* rtamd_multi_exchange_note(const rtamd_ctx* ctx);
 
 /* Replaces RayTracingPass.Dispose (:137-145) and BuildAccelerateStructureSystem.OnDestroy (:165-176). */
 int rtamd_ctx_destroy(rtamd_ctx* ctx);

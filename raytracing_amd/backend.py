@@ -14,7 +14,7 @@ from . import types as T
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librtamd.so")
 _lib = None
 
-EXPORTS = ["rtamd_ctx_create", "rtamd_ctx_destroy", "rtamd_last_error_string", "rtamd_scene_upload",
+EXPORTS = ["rtamd_ctx_create", "rtamd_ctx_create_multi", "rtamd_multi_info", "rtamd_multi_exchange_note", "rtamd_ctx_destroy", "rtamd_last_error_string", "rtamd_scene_upload",
            "rtamd_scene_refresh_objects", "rtamd_sky_upload", "rtamd_render", "rtamd_render_noalloc", "rtamd_accum_reset",
            "rtamd_set_stream", "rtamd_set_tlas_build", "rtamd_tlas_info", "rtamd_last_render_stats", "rtamd_last_trace_kernel_ms", "rtamd_last_handover_stats", "rtamd_composite_add", "rtamd_present", "rtamd_version"]
 
@@ -37,6 +37,10 @@ def lib():
         L.rtamd_last_error_string.argtypes = [C.c_void_p]
         L.rtamd_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.rtamd_ctx_destroy.argtypes = [C.c_void_p]
+        L.rtamd_ctx_create_multi.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_void_p)]
+        L.rtamd_multi_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+        L.rtamd_multi_exchange_note.restype = C.c_char_p
+        L.rtamd_multi_exchange_note.argtypes = [C.c_void_p]
         L.rtamd_scene_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                          C.c_int32, C.c_void_p, C.c_int32]
@@ -86,13 +90,26 @@ class RayTracingPass:
     """Owns one GPU context.  `SetScene` = the buffer bindings of Execute (:83-97),
     `Execute` = the dispatch (:101)."""
 
-    def __init__(self, device=0, settings=None):
+    def __init__(self, device=0, settings=None, devices=None):
+        """device: one GPU ordinal; devices: a list of ordinals for one context over several GPUs
+        (rtamd_ctx_create_multi; the frame is assembled on devices[0])."""
         self.settings = settings or RayTraceSettings()
         self._ctx = C.c_void_p()
-        rc = lib().rtamd_ctx_create(device, C.byref(self._ctx))
+        if devices is not None:
+            arr = (C.c_int32 * len(devices))(*devices)
+            rc = lib().rtamd_ctx_create_multi(arr, len(devices), C.byref(self._ctx))
+            device = devices[0] if len(devices) else 0
+        else:
+            rc = lib().rtamd_ctx_create(device, C.byref(self._ctx))
         if rc != 0:
             raise BackendError(rc, lib().rtamd_last_error_string(None).decode())
         self.device = device
+
+    def MultiInfo(self):
+        n, ranks, ms = C.c_int32(0), C.c_int32(0), C.c_float(0)
+        self._check(lib().rtamd_multi_info(self._ctx, C.byref(n), C.byref(ranks), C.byref(ms)))
+        return {"devices": n.value, "rccl_ranks": ranks.value, "exchange_ms": ms.value,
+                "note": lib().rtamd_multi_exchange_note(self._ctx).decode()}
 
     def Dispose(self):
         if getattr(self, "_ctx", None):

@@ -667,7 +667,6 @@ inline FastLaunchConfig fastLaunchConfig() {
     if (const char* s = getenv("RTAMD_STACK_LIMIT")) { int v = atoi(s); if (v >= kSpillChunk + 4 && v <= kLdsStack) c.stackLimit = v; }
     if (const char* s = getenv("RTAMD_PIPELINE")) c.pool = strcmp(s, "persistent") != 0;
     if (const char* s = getenv("RTAMD_STATS")) c.stats = atoi(s) != 0;
-    if (c.stats) c.pool = false;                // the step counters live in kFast
     return c;
 }
 

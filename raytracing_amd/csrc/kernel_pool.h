@@ -89,10 +89,20 @@ __device__ __forceinline__ Ray poolLoadRay(const PoolRec* rec) {
     return r;
 }
 
+// STATS = true builds a diagnostic variant that also counts, per phase, how often the wave executed
+// it and with how many active lanes (written to `stats`, 16 counters; see launchPool for the names).
+template <bool STATS>
 __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene sc, Sky sky, RenderArgs a, PoolBatch b, int refillBelow,
-                                                                       int nodeMin, int leafGroupMin, int stackLimit, int poolSlots) {
-    constexpr bool STATS = false;
-#define RT_STAT(slot, cond) do { } while (0)
+                                                                       int nodeMin, int leafGroupMin, int stackLimit, int poolSlots,
+                                                                       unsigned long long* stats) {
+    unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define RT_STAT(slot, cond)                                                         \
+    do {                                                                            \
+        if (STATS) {                                                                \
+            unsigned long long m_ = __ballot(cond);                                 \
+            if (m_) { st_[2 * (slot)] += 1; st_[2 * (slot) + 1] += __popcll(m_); }  \
+        }                                                                           \
+    } while (0)
     __shared__ int32_t ldsStack[kLdsStack][kBlockThreads];
     __shared__ float4 ldsNodes[kPoolHotNodes * kHotStride];
     __shared__ uint16_t ldsQueues[kBlockThreads / 64][2][kPoolQueue];
@@ -132,8 +142,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
     int instSp = kNoInstance;
     int spilled = 0;
     int32_t curInst = -1;
-    int deepest = 0;
-    (void)deepest;
+    int deepest = 0;          // STATS: largest stack height of this lane
 #define RT_WORLD_RAY() world
 #include "traverse_macros.inc"
     // a ray that cannot be settled here: its pixel goes to the reference-order kernel (when the path is shaded)
@@ -144,6 +153,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
         {
             const bool fin = !trav && slot >= 0;
             const unsigned long long m = __ballot(fin);
+            RT_STAT(5, fin);
             if (fin) {
                 PoolRec* rec = recs + slot;
                 const bool amb = best.t < RT_INF && secondT < bestNear;   // order-dependent in the reference: see kernel_fast.h
@@ -175,6 +185,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             nAlloc += nNew;
 
             bool goOn = false, ended = false;
+            RT_STAT(0, s >= 0);
             if (s >= 0) {
                 PoolRec* rec = recs + s;
                 // (the whole record at once: one round trip)
@@ -324,6 +335,13 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
 #undef RT_WORLD_RAY
 #undef RT_REDO
 #undef RT_STAT
+    if (STATS) {
+        for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(deepest, off, 64); deepest = o > deepest ? o : deepest; }
+        if (lane == 0) {
+            for (int i = 0; i < 15; i++) if (st_[i]) atomicAdd(stats + i, st_[i]);
+            atomicMax(stats + 15, (unsigned long long)deepest);
+        }
+    }
 }
 
 // Adds the batch's samples to each pixel's running sum, in sample order; the last batch writes
@@ -483,6 +501,10 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         (void)hipGetLastError();
     }
 
+    if (cfg.stats) {
+        if ((e = fs.stats.ensure(16)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(fs.stats.p, 0, 16 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+    }
     for (size_t t0 = 0; t0 < fs.hSuper.size(); t0 += tilesPerChunk) {
         const size_t nt = fs.hSuper.size() - t0 < tilesPerChunk ? fs.hSuper.size() - t0 : tilesPerChunk;
         for (int s0 = 0; s0 < a.spp; s0 += (int)samplesPerBatch) {
@@ -506,11 +528,22 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             }
             if ((e = ph.eventsFor(ph.nTimed)) != hipSuccess) return e;
             if ((e = hipEventRecord(ph.evBegin[ph.nTimed], stream)) != hipSuccess) return e;
-            hipLaunchKernelGGL(kPool, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots);
+            if (cfg.stats) hipLaunchKernelGGL(kPool<true>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots, fs.stats.p);
+            else hipLaunchKernelGGL(kPool<false>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots, (unsigned long long*)nullptr);
             if ((e = hipEventRecord(ph.evEnd[ph.nTimed++], stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(kPoolSum, dim3((b.nWork + 255) / 256), dim3(256), 0, stream, sc, a, b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
+    }
+    if (cfg.stats) {
+        // diagnostic build: per-phase execution counts and active lanes of the whole render, to stderr
+        unsigned long long h[16];
+        if ((e = hipMemcpyAsync(h, fs.stats.p, sizeof(h), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        const char* names[8] = {"shadePass", "nodeStep", "instEnter", "triLeaf(slot boxes)", "triTest", "publishHit", "leafPhase(trav lanes)", "nodeLoop(trav lanes)"};
+        for (int i = 0; i < 8; i++)
+            if (h[2 * i]) fprintf(stderr, "[rtamd stats] kPool %-22s executions %12llu  mean active lanes %6.2f\n", names[i], h[2 * i], (double)h[2 * i + 1] / (double)h[2 * i]);
+        fprintf(stderr, "[rtamd stats] kPool deepest traversal stack %llu of %d entries in LDS\n", h[15], kLdsStack);
     }
     return hipSuccess;
 }

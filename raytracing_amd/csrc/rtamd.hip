@@ -14,11 +14,13 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernel_faithful.h"
 #include "kernel_fast.h"
 #include "kernel_pool.h"
+#include "multi_gpu.h"
 #include "rtamd.h"
 
 static_assert(sizeof(rtamd_node) == 116, "Node stride");
@@ -137,6 +139,15 @@ struct rtamd_ctx {
     int32_t lastRedoPixels = 0;
     float lastKernelMs = 0.f, lastHandoverMs = 0.f, lastTraceMs = 0.f;
     uint64_t lastRays = 0;
+
+    // A context over several GPUs (rtamd_ctx_create_multi) owns one ordinary context per device and
+    // nothing else on the GPUs; subs[0] is the device the finished frame is assembled on.
+    std::vector<rtamd_ctx*> subs;
+    std::vector<ncclComm_t> comms;                    // per sub, when RCCL carries the exchange
+    int rcclRanks = 0;
+    std::string exchangeNote;                         // why RCCL is not in use, if it is not
+    std::vector<DevBuf<unsigned char>> piece, recv;   // per sub: its packed tiles (on its device) / where they land (on subs[0]'s device)
+    float lastExchangeMs = 0.f;
 };
 
 namespace {
@@ -204,9 +215,16 @@ int validateTree(rtamd_ctx* c, const rtamd_node* nodes, int nNodes, int leafLimi
 
 }  // namespace
 
+// A context over several GPUs forwards every call to its per-device contexts (defined further down).
+namespace multi {
+template <typename F> int forEach(rtamd_ctx* c, F call);
+int render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_params* ext, int32_t width, int32_t height,
+           float* out_rgba, int32_t* out_prim_id);
+}  // namespace multi
+
 extern "C" {
 
-const char* rtamd_version(void) { return "rtamd 0.1 gfx950"; }
+const char* rtamd_version(void) { return "rtamd 0.2 gfx950"; }
 
 const char* rtamd_last_error_string(const rtamd_ctx* ctx) {
     return ctx ? ctx->error.c_str() : g_createError.c_str();
@@ -240,6 +258,18 @@ int rtamd_ctx_create(int device_ordinal, rtamd_ctx** out_ctx) {
 
 int rtamd_ctx_destroy(rtamd_ctx* c) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->subs.empty()) {
+        for (ncclComm_t comm : c->comms) if (comm) (void)rt::rccl().CommDestroy(comm);
+        for (size_t d = 0; d < c->subs.size(); d++) {
+            (void)hipSetDevice(c->subs[d]->device);
+            if (d < c->piece.size()) c->piece[d].release();
+        }
+        (void)hipSetDevice(c->subs[0]->device);
+        for (auto& b : c->recv) b.release();
+        for (rtamd_ctx* sub : c->subs) (void)rtamd_ctx_destroy(sub);
+        delete c;
+        return RTAMD_OK;
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->tlas.release(); c->blas.release(); c->blasOffsets.release(); c->vtxOffsets.release(); c->triOffsets.release();
@@ -257,6 +287,7 @@ int rtamd_ctx_destroy(rtamd_ctx* c) {
 
 int rtamd_set_stream(rtamd_ctx* c, void* s) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->subs.empty()) return fail(c, RTAMD_ERR_INVALID_ARG, "a context over several GPUs runs every device on a stream of its own");
     c->stream = s ? (hipStream_t)s : c->ownStream;
     return RTAMD_OK;
 }
@@ -264,12 +295,14 @@ int rtamd_set_stream(rtamd_ctx* c, void* s) {
 int rtamd_set_tlas_build(rtamd_ctx* c, int32_t mode) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (mode < RTAMD_TLAS_BUILD_AUTO || mode > RTAMD_TLAS_BUILD_DEVICE) return fail(c, RTAMD_ERR_INVALID_ARG, "unknown TLAS build mode");
+    if (!c->subs.empty()) return multi::forEach(c, [&](rtamd_ctx* sub) { return rtamd_set_tlas_build(sub, mode); });
     c->fast.tlasBuildMode = mode;
     return RTAMD_OK;
 }
 
 int rtamd_tlas_info(const rtamd_ctx* c, int32_t* nodes, int32_t* levels, int32_t* built_on_device) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->subs.empty()) return rtamd_tlas_info(c->subs[0], nodes, levels, built_on_device);
     if (!c->haveScene) return RTAMD_ERR_NO_SCENE;
     if (nodes) *nodes = c->fast.nTlasNodes;
     if (levels) *levels = c->fast.tlasDepth;
@@ -301,6 +334,14 @@ int rtamd_scene_upload(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas, cons
                        const rtamd_vertex* verts, int32_t nVerts, const int32_t* triOffsets, const rtamd_int3* tris,
                        int32_t nTris, int32_t nBlas, const rtamd_object_property* objects, int32_t nObjects) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->subs.empty()) {
+        // the scene is replicated: every device re-packs and uploads it, all at once
+        const int rc = multi::forEach(c, [&](rtamd_ctx* sub) {
+            return rtamd_scene_upload(sub, tlas, nTlas, blasOffsets, blas, nBlasNodes, vtxOffsets, verts, nVerts, triOffsets, tris, nTris, nBlas, objects, nObjects);
+        });
+        c->haveScene = rc == RTAMD_OK;
+        return rc;
+    }
     if (!tlas || !blasOffsets || !blas || !vtxOffsets || !verts || !triOffsets || !tris || !objects)
         return fail(c, RTAMD_ERR_INVALID_ARG, "NULL scene buffer");
     if (nTlas < 2 || nBlasNodes < 2 || nVerts < 1 || nTris < 1 || nBlas < 1 || nObjects < 1)
@@ -354,6 +395,7 @@ int rtamd_scene_upload(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas, cons
 int rtamd_scene_refresh_objects(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas,
                                 const rtamd_object_property* objects, int32_t nObjects) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->subs.empty()) return multi::forEach(c, [&](rtamd_ctx* sub) { return rtamd_scene_refresh_objects(sub, tlas, nTlas, objects, nObjects); });
     if (!c->haveScene) return fail(c, RTAMD_ERR_NO_SCENE, "refresh before a scene upload");
     if (!tlas || !objects || nTlas < 2) return fail(c, RTAMD_ERR_INVALID_ARG, "NULL / empty buffer");
     if (nObjects != c->nObjects) return fail(c, RTAMD_ERR_INVALID_ARG, "object count differs from the uploaded scene");
@@ -367,6 +409,7 @@ int rtamd_scene_refresh_objects(rtamd_ctx* c, const rtamd_node* tlas, int32_t nT
 
 int rtamd_sky_upload(rtamd_ctx* c, const float* rgba, int32_t w, int32_t h) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->subs.empty()) return multi::forEach(c, [&](rtamd_ctx* sub) { return rtamd_sky_upload(sub, rgba, w, h); });
     HIP_TRY(c, hipSetDevice(c->device));
     if (!rgba || w <= 0 || h <= 0) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -381,6 +424,7 @@ int rtamd_sky_upload(rtamd_ctx* c, const float* rgba, int32_t w, int32_t h) {
 
 int rtamd_accum_reset(rtamd_ctx* c) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->subs.empty()) return multi::forEach(c, [&](rtamd_ctx* sub) { return rtamd_accum_reset(sub); });
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->accum.p) HIP_TRY(c, hipMemsetAsync(c->accum.p, 0, c->accum.n * sizeof(float4), c->stream));
     return RTAMD_OK;
@@ -589,15 +633,329 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
     return RTAMD_OK;
 }
 
+// ---------------------------------------------------------------- several GPUs behind one context
+namespace multi {
+
+// Run `call` on every per-device context, each on a host thread of its own (the calls block);
+// the first failure is reported with that device's message.
+template <typename F>
+int forEach(rtamd_ctx* c, F call) {
+    const size_t n = c->subs.size();
+    std::vector<int> rc(n, RTAMD_OK);
+    std::vector<std::thread> th;
+    try {
+        for (size_t d = 1; d < n; d++) th.emplace_back([&, d] { rc[d] = call(c->subs[d]); });
+    } catch (...) {
+        for (auto& t : th) t.join();
+        return fail(c, RTAMD_ERR_OUT_OF_MEMORY, "could not start a host thread per device");
+    }
+    rc[0] = call(c->subs[0]);
+    for (auto& t : th) t.join();
+    for (size_t d = 0; d < n; d++)
+        if (rc[d] != RTAMD_OK) return fail(c, rc[d], "device " + std::to_string(c->subs[d]->device) + ": " + c->subs[d]->error);
+    return RTAMD_OK;
+}
+
+#define RCCL_TRY(c, expr)                                                                                 \
+    do {                                                                                                  \
+        ncclResult_t r_ = (expr);                                                                         \
+        if (r_ != ncclSuccess) return fail(c, RTAMD_ERR_HIP, std::string(#expr) + ": " + rt::rccl().GetErrorString(r_)); \
+    } while (0)
+
+// Move device d's packed piece (bytes) to the receive buffer on the first device.
+static int gatherPieces(rtamd_ctx* c, const std::vector<size_t>& bytes) {
+    const size_t n = c->subs.size();
+    rtamd_ctx* root = c->subs[0];
+    if (!c->comms.empty()) {
+        rt::RcclApi& api = rt::rccl();
+        RCCL_TRY(c, api.GroupStart());
+        for (size_t d = 1; d < n; d++) {
+            if (!bytes[d]) continue;
+            RCCL_TRY(c, api.Recv(c->recv[d].p, bytes[d], ncclUint8, (int)d, c->comms[0], root->stream));
+            RCCL_TRY(c, api.Send(c->piece[d].p, bytes[d], ncclUint8, 0, c->comms[d], c->subs[d]->stream));
+        }
+        RCCL_TRY(c, api.GroupEnd());
+        return RTAMD_OK;
+    }
+    for (size_t d = 1; d < n; d++) {
+        if (!bytes[d]) continue;
+        HIP_TRY(c, hipSetDevice(c->subs[d]->device));
+        HIP_TRY(c, hipStreamSynchronize(c->subs[d]->stream));          // the piece is packed
+        HIP_TRY(c, hipSetDevice(root->device));
+        HIP_TRY(c, hipMemcpyPeerAsync(c->recv[d].p, root->device, c->piece[d].p, c->subs[d]->device, bytes[d], root->stream));
+    }
+    return RTAMD_OK;
+}
+
+template <typename T>
+static int packOn(rtamd_ctx* c, size_t d, const T* frame, size_t offset, int w, int h, uint32_t nTiles) {
+    rtamd_ctx* sub = c->subs[d];
+    HIP_TRY(c, hipSetDevice(sub->device));
+    const uint32_t n = nTiles * 1024u;
+    hipLaunchKernelGGL((rt::kPackShard<T>), dim3((n + 255) / 256), dim3(256), 0, sub->stream, frame, (T*)(c->piece[d].p + offset), w, h, (int)d,
+                       (int)c->subs.size(), nTiles);
+    HIP_TRY(c, hipGetLastError());
+    return RTAMD_OK;
+}
+template <typename T>
+static int unpackOn(rtamd_ctx* c, size_t d, T* frame, size_t offset, int w, int h, uint32_t nTiles, const rt::RenderArgs& rect) {
+    rtamd_ctx* root = c->subs[0];
+    const uint32_t n = nTiles * 1024u;
+    hipLaunchKernelGGL((rt::kUnpackShard<T>), dim3((n + 255) / 256), dim3(256), 0, root->stream, (const T*)(c->recv[d].p + offset), frame, w, h, (int)d,
+                       (int)c->subs.size(), nTiles, rect.tileX, rect.tileY, rect.tileW, rect.tileH);
+    HIP_TRY(c, hipGetLastError());
+    return RTAMD_OK;
+}
+
+int render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_params* ext, int32_t width, int32_t height,
+           float* out_rgba, int32_t* out_prim_id) {
+    if (!frame) return fail(c, RTAMD_ERR_INVALID_ARG, "frame is NULL");
+    if (width <= 0 || height <= 0 || (int64_t)width * height > (1ll << 30)) return fail(c, RTAMD_ERR_INVALID_ARG, "bad image size");
+    if (!c->haveScene) return fail(c, RTAMD_ERR_NO_SCENE, "render before a scene upload");
+    rtamd_ext_params e;
+    std::memset(&e, 0, sizeof(e));
+    e.struct_size = sizeof(e); e.mode = RTAMD_MODE_REF; e.spp = 1;
+    if (ext) {
+        if (ext->struct_size != sizeof(rtamd_ext_params)) return fail(c, RTAMD_ERR_INVALID_ARG, "ext.struct_size mismatch");
+        e = *ext;
+    }
+    if (e.shard_count > 1) return fail(c, RTAMD_ERR_INVALID_ARG, "a context over several GPUs shards the frame itself: leave shard_count at 0");
+    const int n = (int)c->subs.size();
+    const bool bySamples = (e.flags & RTAMD_FLAG_SHARD_SAMPLES) && e.mode == RTAMD_MODE_PT && n > 1;
+    if (bySamples && (e.flags & RTAMD_FLAG_ACCUMULATE)) return fail(c, RTAMD_ERR_INVALID_ARG, "RTAMD_FLAG_ACCUMULATE needs tile sharding on a context over several GPUs");
+    if (bySamples && e.spp < n) return fail(c, RTAMD_ERR_INVALID_ARG, "sample sharding needs at least one sample per GPU");
+    if (e.mode == RTAMD_MODE_PT && (e.spp < 1 || e.max_bounces < 0 || e.sample_offset < 0))
+        return fail(c, RTAMD_ERR_INVALID_ARG, "PT mode needs spp >= 1, max_bounces >= 0, sample_offset >= 0");
+    const uint32_t callerFlags = e.flags;
+    e.flags &= ~(uint32_t)RTAMD_FLAG_SHARD_SAMPLES;
+    const size_t npix = (size_t)width * height;
+    rtamd_ctx* root = c->subs[0];
+    // rendered rectangle, as renderCore clips it
+    rt::RenderArgs rect;
+    std::memset(&rect, 0, sizeof(rect));
+    rect.tileX = 0; rect.tileY = 0; rect.tileW = width; rect.tileH = height;
+    bool partial = false;
+    if (e.tile_w > 0 && e.tile_h > 0) {
+        int x0 = e.tile_x < 0 ? 0 : e.tile_x, y0 = e.tile_y < 0 ? 0 : e.tile_y;
+        int x1 = e.tile_x + e.tile_w > width ? width : e.tile_x + e.tile_w;
+        int y1 = e.tile_y + e.tile_h > height ? height : e.tile_y + e.tile_h;
+        rect.tileX = x0; rect.tileY = y0; rect.tileW = x1 > x0 ? x1 - x0 : 0; rect.tileH = y1 > y0 ? y1 - y0 : 0;
+        partial = true;
+    }
+    float* const callerT = e.out_t;
+    rtamd_counters* const callerCounters = e.out_counters;
+
+    // per-device frames: every device renders into buffers on its own card (the staging buffers of its
+    // context); the first device's are the ones the frame is assembled in
+    for (int d = 0; d < n; d++) {
+        rtamd_ctx* sub = c->subs[d];
+        HIP_TRY(c, hipSetDevice(sub->device));
+        const bool wantIds = out_prim_id && (d == 0 || !bySamples), wantT = callerT && (d == 0 || !bySamples);
+        if (out_rgba) HIP_TRY(c, sub->outRgba.alloc(npix));
+        if (wantIds) HIP_TRY(c, sub->outIds.alloc(npix * 2));
+        if (wantT) HIP_TRY(c, sub->outT.alloc(npix));
+        if (d == 0 && partial) {
+            // pixels outside the rectangle keep the caller's values
+            if (out_rgba) HIP_TRY(c, hipMemcpyAsync(sub->outRgba.p, out_rgba, npix * sizeof(float4), hipMemcpyDefault, sub->stream));
+            if (out_prim_id) HIP_TRY(c, hipMemcpyAsync(sub->outIds.p, out_prim_id, npix * 2 * sizeof(int32_t), hipMemcpyDefault, sub->stream));
+            if (callerT) HIP_TRY(c, hipMemcpyAsync(sub->outT.p, callerT, npix * sizeof(float), hipMemcpyDefault, sub->stream));
+        }
+        if (d > 0 && bySamples && out_rgba) HIP_TRY(c, hipMemsetAsync(sub->outRgba.p, 0, npix * sizeof(float4), sub->stream));   // un-rendered pixels add nothing
+    }
+    std::vector<rtamd_counters> counters((size_t)n);
+    std::memset(counters.data(), 0, sizeof(rtamd_counters) * (size_t)n);
+    const int rc = forEach(c, [&](rtamd_ctx* sub) -> int {
+        int d = 0;
+        while (c->subs[d] != sub) d++;
+        rtamd_ext_params ed = e;
+        const bool wantIds = out_prim_id && (d == 0 || !bySamples), wantT = callerT && (d == 0 || !bySamples);
+        ed.out_t = wantT ? sub->outT.p : nullptr;
+        ed.out_counters = callerCounters ? &counters[(size_t)d] : nullptr;
+        if (bySamples) {
+            const int base = e.spp / n, extra = e.spp % n;
+            ed.spp = base + (d < extra ? 1 : 0);
+            ed.sample_offset = e.sample_offset + d * base + (d < extra ? d : extra);
+            ed.flags |= RTAMD_FLAG_OUTPUT_SUM;
+        } else if (n > 1) {
+            ed.shard_rank = d; ed.shard_count = n;
+        }
+        return renderCore(sub, frame, &ed, width, height, out_rgba ? (float*)sub->outRgba.p : nullptr, wantIds ? sub->outIds.p : nullptr, false);
+    });
+    if (rc != RTAMD_OK) return rc;
+
+    // ---- the exchange step
+    hipEvent_t ev0 = root->evStart, ev1 = root->evStop;
+    HIP_TRY(c, hipSetDevice(root->device));
+    HIP_TRY(c, hipEventRecord(ev0, root->stream));
+    if (n > 1 && !bySamples) {
+        // gather: rgba (16 B), ids (8 B), t (4 B) of a device's tiles go in one piece
+        std::vector<size_t> bytes((size_t)n, 0);
+        std::vector<uint32_t> tiles((size_t)n, 0);
+        const size_t per = (out_rgba ? 16 : 0) + (out_prim_id ? 8 : 0) + (callerT ? 4 : 0);
+        for (int d = 1; d < n; d++) {
+            tiles[d] = rt::shardTileCount(width, height, d, n);
+            bytes[d] = (size_t)tiles[d] * 1024 * per;
+            if (!bytes[d]) continue;
+            HIP_TRY(c, hipSetDevice(c->subs[d]->device));
+            HIP_TRY(c, c->piece[d].alloc(bytes[d]));
+            HIP_TRY(c, hipSetDevice(root->device));
+            HIP_TRY(c, c->recv[d].alloc(bytes[d]));
+            const size_t offIds = out_rgba ? (size_t)tiles[d] * 1024 * 16 : 0, offT = offIds + (out_prim_id ? (size_t)tiles[d] * 1024 * 8 : 0);
+            int prc;
+            if (out_rgba && (prc = packOn<float4>(c, d, c->subs[d]->outRgba.p, 0, width, height, tiles[d]))) return prc;
+            if (out_prim_id && (prc = packOn<int2>(c, d, (const int2*)c->subs[d]->outIds.p, offIds, width, height, tiles[d]))) return prc;
+            if (callerT && (prc = packOn<float>(c, d, c->subs[d]->outT.p, offT, width, height, tiles[d]))) return prc;
+        }
+        HIP_TRY(c, hipSetDevice(root->device));
+        int grc = gatherPieces(c, bytes);
+        if (grc) return grc;
+        HIP_TRY(c, hipSetDevice(root->device));
+        for (int d = 1; d < n; d++) {
+            if (!bytes[d]) continue;
+            const size_t offIds = out_rgba ? (size_t)tiles[d] * 1024 * 16 : 0, offT = offIds + (out_prim_id ? (size_t)tiles[d] * 1024 * 8 : 0);
+            int prc;
+            if (out_rgba && (prc = unpackOn<float4>(c, d, root->outRgba.p, 0, width, height, tiles[d], rect))) return prc;
+            if (out_prim_id && (prc = unpackOn<int2>(c, d, (int2*)root->outIds.p, offIds, width, height, tiles[d], rect))) return prc;
+            if (callerT && (prc = unpackOn<float>(c, d, root->outT.p, offT, width, height, tiles[d], rect))) return prc;
+        }
+    } else if (n > 1 && out_rgba) {
+        // reduce the sum buffers onto the first device
+        if (!c->comms.empty()) {
+            rt::RcclApi& api = rt::rccl();
+            RCCL_TRY(c, api.GroupStart());
+            for (int d = 0; d < n; d++)
+                RCCL_TRY(c, api.Reduce(c->subs[d]->outRgba.p, d == 0 ? root->outRgba.p : nullptr, npix * 4, ncclFloat32, ncclSum, 0, c->comms[d], c->subs[d]->stream));
+            RCCL_TRY(c, api.GroupEnd());
+        } else {
+            HIP_TRY(c, c->recv[1].alloc(npix * sizeof(float4)));
+            for (int d = 1; d < n; d++) {
+                HIP_TRY(c, hipSetDevice(c->subs[d]->device));
+                HIP_TRY(c, hipStreamSynchronize(c->subs[d]->stream));
+                HIP_TRY(c, hipSetDevice(root->device));
+                HIP_TRY(c, hipMemcpyPeerAsync(c->recv[1].p, root->device, c->subs[d]->outRgba.p, c->subs[d]->device, npix * sizeof(float4), root->stream));
+                hipLaunchKernelGGL(rt::kAddSums, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, root->stream, root->outRgba.p, (const float4*)c->recv[1].p, npix);
+                HIP_TRY(c, hipGetLastError());
+            }
+        }
+        if (!(callerFlags & RTAMD_FLAG_OUTPUT_SUM)) {
+            hipLaunchKernelGGL(rt::kSumsToMean, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, root->stream, root->outRgba.p, npix, width, rect.tileX, rect.tileY,
+                               rect.tileW, rect.tileH);
+            HIP_TRY(c, hipGetLastError());
+        }
+    } else if (bySamples && out_rgba && !(callerFlags & RTAMD_FLAG_OUTPUT_SUM)) {
+        hipLaunchKernelGGL(rt::kSumsToMean, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, root->stream, root->outRgba.p, npix, width, rect.tileX, rect.tileY,
+                           rect.tileW, rect.tileH);
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipEventRecord(ev1, root->stream));
+    // hand the assembled frame to the caller (host memory, or device memory on any GPU)
+    if (out_rgba) HIP_TRY(c, hipMemcpyAsync(out_rgba, root->outRgba.p, npix * sizeof(float4), hipMemcpyDefault, root->stream));
+    if (out_prim_id) HIP_TRY(c, hipMemcpyAsync(out_prim_id, root->outIds.p, npix * 2 * sizeof(int32_t), hipMemcpyDefault, root->stream));
+    if (callerT) HIP_TRY(c, hipMemcpyAsync(callerT, root->outT.p, npix * sizeof(float), hipMemcpyDefault, root->stream));
+    for (int d = n - 1; d >= 0; d--) {
+        HIP_TRY(c, hipSetDevice(c->subs[d]->device));
+        HIP_TRY(c, hipStreamSynchronize(c->subs[d]->stream));
+    }
+    float xms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&xms, ev0, ev1));
+    c->lastExchangeMs = xms;
+    // the slowest device sets the frame time; work adds up
+    c->lastKernelMs = c->lastTraceMs = c->lastHandoverMs = 0.f;
+    c->lastRays = 0; c->lastRedoPixels = 0;
+    for (rtamd_ctx* sub : c->subs) {
+        c->lastKernelMs = sub->lastKernelMs > c->lastKernelMs ? sub->lastKernelMs : c->lastKernelMs;
+        c->lastTraceMs = sub->lastTraceMs > c->lastTraceMs ? sub->lastTraceMs : c->lastTraceMs;
+        c->lastHandoverMs = sub->lastHandoverMs > c->lastHandoverMs ? sub->lastHandoverMs : c->lastHandoverMs;
+        c->lastRays += sub->lastRays;
+        c->lastRedoPixels += sub->lastRedoPixels;
+    }
+    if (callerCounters) {
+        rtamd_counters t;
+        std::memset(&t, 0, sizeof(t));
+        for (const rtamd_counters& k : counters) {
+            t.rays += k.rays; t.nodes += k.nodes; t.tris += k.tris; t.instances += k.instances; t.hits += k.hits; t.reserved += k.reserved;
+            t.max_blas_stack = k.max_blas_stack > t.max_blas_stack ? k.max_blas_stack : t.max_blas_stack;
+            t.max_tlas_stack = k.max_tlas_stack > t.max_tlas_stack ? k.max_tlas_stack : t.max_tlas_stack;
+        }
+        *callerCounters = t;
+    }
+    return RTAMD_OK;
+}
+
+}  // namespace multi
+
 extern "C" {
+
+int rtamd_ctx_create_multi(const int32_t* device_ordinals, int32_t n_devices, rtamd_ctx** out_ctx) {
+    if (!out_ctx) return fail(nullptr, RTAMD_ERR_INVALID_ARG, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    if (!device_ordinals || n_devices < 1 || n_devices > kMaxDevices) return fail(nullptr, RTAMD_ERR_INVALID_ARG, "device list is NULL, empty or longer than 64");
+    rtamd_ctx* c = new (std::nothrow) rtamd_ctx();
+    if (!c) return fail(nullptr, RTAMD_ERR_OUT_OF_MEMORY, "host allocation failed");
+    c->device = device_ordinals[0];
+    bool distinct = true;
+    for (int d = 0; d < n_devices; d++) {
+        rtamd_ctx* sub = nullptr;
+        const int rc = rtamd_ctx_create(device_ordinals[d], &sub);
+        if (rc != RTAMD_OK) {
+            const std::string why = g_createError;
+            for (rtamd_ctx* made : c->subs) (void)rtamd_ctx_destroy(made);
+            delete c;
+            return fail(nullptr, rc, "device " + std::to_string(device_ordinals[d]) + ": " + why);
+        }
+        c->subs.push_back(sub);
+        for (int k = 0; k < d; k++) distinct = distinct && device_ordinals[k] != device_ordinals[d];
+    }
+    c->piece.resize((size_t)n_devices);
+    c->recv.resize((size_t)n_devices < 2 ? 2 : (size_t)n_devices);
+    // peer access for the copies that carry the exchange when RCCL does not
+    for (int d = 1; d < n_devices; d++)
+        if (device_ordinals[d] != device_ordinals[0]) {
+            (void)hipSetDevice(device_ordinals[0]);
+            if (hipDeviceEnablePeerAccess(device_ordinals[d], 0) != hipSuccess) (void)hipGetLastError();
+            (void)hipSetDevice(device_ordinals[d]);
+            if (hipDeviceEnablePeerAccess(device_ordinals[0], 0) != hipSuccess) (void)hipGetLastError();
+        }
+    // RCCL communicator over the devices (one rank per device, this process holds them all)
+    const char* off = getenv("RTAMD_NO_RCCL");
+    if (off && atoi(off) != 0) c->exchangeNote = "RCCL switched off by RTAMD_NO_RCCL";
+    else if (!distinct) c->exchangeNote = "a device is listed twice: RCCL takes one rank per GPU, peer copies carry the exchange";
+    else {
+        std::string why;
+        if (rt::rccl().load(why)) {
+            std::vector<int> devs(device_ordinals, device_ordinals + n_devices);
+            c->comms.assign((size_t)n_devices, nullptr);
+            const ncclResult_t r = rt::rccl().CommInitAll(c->comms.data(), n_devices, devs.data());
+            if (r != ncclSuccess) {
+                c->exchangeNote = std::string("ncclCommInitAll: ") + rt::rccl().GetErrorString(r) + "; peer copies carry the exchange";
+                c->comms.clear();
+            } else if (rt::rccl().CommCount(c->comms[0], &c->rcclRanks) != ncclSuccess) c->rcclRanks = n_devices;
+        } else c->exchangeNote = why + "; peer copies carry the exchange";
+    }
+    (void)hipSetDevice(device_ordinals[0]);
+    *out_ctx = c;
+    return RTAMD_OK;
+}
+
+int rtamd_multi_info(const rtamd_ctx* c, int32_t* n_devices, int32_t* rccl_ranks, float* last_exchange_ms) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (n_devices) *n_devices = c->subs.empty() ? 1 : (int32_t)c->subs.size();
+    if (rccl_ranks) *rccl_ranks = c->rcclRanks;
+    if (last_exchange_ms) *last_exchange_ms = c->lastExchangeMs;
+    return RTAMD_OK;
+}
+
+const char* rtamd_multi_exchange_note(const rtamd_ctx* c) { return c ? c->exchangeNote.c_str() : ""; }
 
 int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_params* ext, int32_t width,
                  int32_t height, float* out_rgba, int32_t* out_prim_id) {
+    if (c && !c->subs.empty()) return multi::render(c, frame, ext, width, height, out_rgba, out_prim_id);
     return renderCore(c, frame, ext, width, height, out_rgba, out_prim_id, false);
 }
 
 int rtamd_render_noalloc(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_params* ext, int32_t width,
                          int32_t height, float* out_rgba_device, int32_t* out_prim_id_device) {
+    if (c && !c->subs.empty()) return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_noalloc: not available on a context over several GPUs (the exchange buffers are sized to the frame)");
     return renderCore(c, frame, ext, width, height, out_rgba_device, out_prim_id_device, true);
 }
 
@@ -642,6 +1000,7 @@ __global__ void kCompositeAdd(const float4* src, uchar4* dst, size_t n) {
 
 extern "C" int rtamd_composite_add(rtamd_ctx* c, const float* src, uint8_t* dst, int32_t width, int32_t height) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->subs.empty()) return rtamd_composite_add(c->subs[0], src, dst, width, height);
     if (!src || !dst || width <= 0 || height <= 0) return fail(c, RTAMD_ERR_INVALID_ARG, "NULL buffer or bad size");
     HIP_TRY(c, hipSetDevice(c->device));
     size_t n = (size_t)width * height;
@@ -684,6 +1043,7 @@ __global__ void kPresent(const float4* src, uchar4* dst, size_t n, int tonemap, 
 extern "C" int rtamd_present(rtamd_ctx* c, const float* src, uint8_t* dst, int32_t width, int32_t height, int32_t tonemap,
                              float exposure, float gamma) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->subs.empty()) return rtamd_present(c->subs[0], src, dst, width, height, tonemap, exposure, gamma);
     if (!src || !dst || width <= 0 || height <= 0) return fail(c, RTAMD_ERR_INVALID_ARG, "NULL buffer or bad size");
     if (tonemap != RTAMD_TONEMAP_CLAMP && tonemap != RTAMD_TONEMAP_REINHARD) return fail(c, RTAMD_ERR_INVALID_ARG, "unknown tone map");
     if (!(exposure >= 0.0f) || !(gamma >= 0.0f)) return fail(c, RTAMD_ERR_INVALID_ARG, "exposure and gamma must be >= 0");
