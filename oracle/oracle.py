@@ -13,7 +13,9 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_DIR, "_build", "librt_oracle.so")
+_SO_RECIPROCAL = os.path.join(_DIR, "_build", "librt_oracle_reciprocal.so")      # divisions as reciprocal multiplications (counting only)
 _lib = None
+_lib_reciprocal = None
 
 
 class _Scene(C.Structure):
@@ -39,9 +41,20 @@ class _Counters(C.Structure):
 
 def build():
     src = os.path.join(_DIR, "rt_oracle.cpp")
-    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    if any(not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src) for so in (_SO, _SO_RECIPROCAL)):
         subprocess.run(["make", "-C", _DIR], check=True)
     return _SO
+
+
+def lib_reciprocal():
+    """The build with RT_ORACLE_RECIPROCAL_DIVISIONS: same entry points, reciprocal multiplications
+    where the shader text has a `/` by a constant or per-frame value."""
+    global _lib_reciprocal
+    if _lib_reciprocal is None:
+        if not os.path.exists(_SO_RECIPROCAL):
+            build()
+        _lib_reciprocal = C.CDLL(_SO_RECIPROCAL)
+    return _lib_reciprocal
 
 
 def lib():
@@ -84,8 +97,9 @@ def _scene(b, sky):
 
 def render(buffers, frame, width, height, sky=None, mode=0, spp=1, max_bounces=8, seed=0, sample_offset=0,
            tile=None, shard=None, flags=0, nthreads=1, want_rgba=True, want_ids=True, want_t=True,
-           rgba=None, ids=None, t=None):
-    """Returns dict(rgba, ids, t, counters, overflow)."""
+           rgba=None, ids=None, t=None, reciprocal=False):
+    """Returns dict(rgba, ids, t, counters, overflow).  reciprocal=True renders with the shader's divisions
+    read as multiplications by rounded reciprocals instead of the declared true divisions."""
     sky = None if sky is None else np.ascontiguousarray(sky, dtype=np.float32)
     sc = _scene(buffers, sky)
     p = _Params()
@@ -102,7 +116,7 @@ def render(buffers, frame, width, height, sky=None, mode=0, spp=1, max_bounces=8
         t = np.zeros((height, width), dtype=np.float32)
     cnt = _Counters()
     frame = np.ascontiguousarray(frame)
-    rc = lib().oracle_render(C.byref(sc), _p(frame), C.byref(p), width, height, _p(rgba), _p(ids), _p(t), C.byref(cnt))
+    rc = (lib_reciprocal() if reciprocal else lib()).oracle_render(C.byref(sc), _p(frame), C.byref(p), width, height, _p(rgba), _p(ids), _p(t), C.byref(cnt))
     counters = {k: int(getattr(cnt, k)) for k, _ in cnt._fields_}
     return dict(rgba=rgba, ids=ids, t=t, counters=counters, overflow=rc != 0)
 

@@ -13,9 +13,8 @@
 //     (build with -ffp-contract=off), subnormals kept;
 //   * dot(a,b)   = (a.x*b.x + a.y*b.y) + a.z*b.z
 //   * mul(M,v)   = per row ((m0*v.x + m1*v.y) + m2*v.z) [+ m3 when w == 1]
-//   * normalize  = v * (1 / sqrt(dot(v,v)))  (one true division, true sqrt; HLSL's own form is v * rsqrt)
-//   * a division by a constant or by a per-frame value (pi, image size, sky size, the roulette sum) is a
-//     multiplication by its correctly rounded reciprocal, as an HLSL compiler emits it
+//   * normalize  = v / sqrt(dot(v,v))  (three true divisions, true sqrt; HLSL's own form is v * rsqrt)
+//   * every `/` in the shader text is a true division (image size :439, -PI :407-408, roulette sum :395)
 //   * reflect    = i - (2*dot(n,i))*n
 //   * min / max  = fminf / fmaxf (a NaN operand is ignored)
 //   * 1.#INF     = +infinity
@@ -105,9 +104,21 @@ static inline float dot(float3 a, float3 b) { return (a.x * b.x + a.y * b.y) + a
 static inline float3 cross(float3 a, float3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
+// Every `/` of the shader text is a true IEEE division (uv / float2(width,height) .compute:439,
+// / -PI :407-408, specChance /= sum :395) and normalize(v) = v / sqrt(dot(v,v)).
+// RT_ORACLE_RECIPROCAL_DIVISIONS builds the other reading — a division by a constant or per-frame
+// value is a multiplication by its rounded reciprocal and normalize is v * (1 / sqrt(dot)), the forms
+// an HLSL compiler may emit — only to COUNT how many primary ids, t values and 8-bit REF pixels the
+// choice moves (tests/test_oracle.py): a few dozen primary ids per 1080p frame, which is why the
+// literal reading is the definition and the kernels follow it.
 static inline float3 normalize(float3 v) {
+#ifndef RT_ORACLE_RECIPROCAL_DIVISIONS
+    float l = std::sqrt(dot(v, v));
+    return {v.x / l, v.y / l, v.z / l};
+#else
     float r = 1.0f / std::sqrt(dot(v, v));
     return {v.x * r, v.y * r, v.z * r};
+#endif
 }
 // fminf / fmaxf semantics (the non-NaN operand wins) without the libm call.
 static inline float ofmin(float a, float b) { float r = a < b ? a : b; return b != b ? a : r; }
@@ -225,6 +236,15 @@ static inline Ray CreateRay(float3 origin, float3 direction) { // .compute:135-1
     r.energy = f3(1.0f, 1.0f, 1.0f);
     r.invDir = f3(1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z);
     return r;
+}
+
+// CSMain: uv = (id.xy + _PixelOffset) / (w,h) * 2 - 1.  .compute:439
+static inline float pixelToNdc(int p, float offset, int extent) {
+#ifndef RT_ORACLE_RECIPROCAL_DIVISIONS
+    return ((float)p + offset) / (float)extent * 2.0f - 1.0f;
+#else
+    return ((float)p + offset) * (1.0f / (float)extent) * 2.0f - 1.0f;
+#endif
 }
 
 static inline Ray CreateCameraRay(const FrameCBuffer& cb, float u, float v) { // .compute:145-157
@@ -431,8 +451,13 @@ static inline float3 sampleSky(const Scene& sc, float u, float v) {
 
 // Miss branch of Shade.  .compute:402-410
 static inline float3 shadeMiss(const Scene& sc, float3 dir) {
+#ifndef RT_ORACLE_RECIPROCAL_DIVISIONS
+    float theta = acosDecl(dir.y) / -PI;
+    float phi = atan2Decl(dir.x, -dir.z) / -PI * 0.5f;
+#else
     float theta = acosDecl(dir.y) * NEG_INV_PI;
     float phi = atan2Decl(dir.x, -dir.z) * NEG_INV_PI * 0.5f;
+#endif
     return sampleSky(sc, phi, theta);
 }
 
@@ -499,9 +524,14 @@ static inline float3 tracePath(Tracer& tr, Ray ray, uint32_t key, int maxBounces
         float diffChance = energyOf(alb);
         float sum = specChance + diffChance;
         if (!(sum > 0.0f)) break;
+#ifndef RT_ORACLE_RECIPROCAL_DIVISIONS
+        specChance = specChance / sum;
+        diffChance = diffChance / sum;
+#else
         float rsum = 1.0f / sum;
         specChance = specChance * rsum;
         diffChance = diffChance * rsum;
+#endif
         float roulette = rngDraw(key, 2u + 3u * (uint32_t)b);
         float3 dir;
         if (roulette < specChance) {
@@ -542,8 +572,8 @@ static void renderRows(const Scene& sc, const FrameCBuffer& cb, const Params& p,
             size_t pix = (size_t)y * width + x;
             // CSMain: uv = (id.xy + _PixelOffset) / (w,h) * 2 - 1.  .compute:439
             if (p.mode == 0 || ids || tout) {
-                float u = ((float)x + cb.PixelOffset[0]) * (1.0f / (float)width) * 2.0f - 1.0f;
-                float v = ((float)y + cb.PixelOffset[1]) * (1.0f / (float)height) * 2.0f - 1.0f;
+                float u = pixelToNdc(x, cb.PixelOffset[0], width);
+                float v = pixelToNdc(y, cb.PixelOffset[1], height);
                 Ray cam = CreateCameraRay(cb, u, v);
                 float px[4];
                 RayHit h;
@@ -563,8 +593,8 @@ static void renderRows(const Scene& sc, const FrameCBuffer& cb, const Params& p,
                     uint32_t key = rngKey(p.seed, (uint32_t)pix, (uint32_t)(p.sample_offset + s));
                     float jx = cb.PixelOffset[0], jy = cb.PixelOffset[1];
                     if (!(p.flags & 2u)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
-                    float u = ((float)x + jx) * (1.0f / (float)width) * 2.0f - 1.0f;
-                    float v = ((float)y + jy) * (1.0f / (float)height) * 2.0f - 1.0f;
+                    float u = pixelToNdc(x, jx, width);
+                    float v = pixelToNdc(y, jy, height);
                     Ray cam = CreateCameraRay(cb, u, v);
                     sum = sum + tracePath(tr, cam, key, p.max_bounces);
                 }
@@ -641,8 +671,8 @@ int oracle_bruteforce_primary(const Scene* sc, const FrameCBuffer* cb, int width
     for (int y = 0; y < height; y++)
         for (int x = 0; x < width; x++) {
             size_t pix = (size_t)y * width + x;
-            float u = ((float)x + cb->PixelOffset[0]) * (1.0f / (float)width) * 2.0f - 1.0f;
-            float v = ((float)y + cb->PixelOffset[1]) * (1.0f / (float)height) * 2.0f - 1.0f;
+            float u = pixelToNdc(x, cb->PixelOffset[0], width);
+            float v = pixelToNdc(y, cb->PixelOffset[1], height);
             Ray ray = CreateCameraRay(*cb, u, v);
             float best = INF; int bo = -1, bt = -1, nt = 0;
             for (int o = 0; o < sc->nObjects; o++) {

@@ -60,12 +60,16 @@ def build_host(force=False):
 
 
 def build_oracle(force=False):
+    """The checker, twice: the declared arithmetic (every `/` of the shader a true division), and the
+    reciprocal-multiplication reading (used only to count what the choice between the two moves)."""
     odir = os.path.join(ROOT, "oracle")
     src = os.path.join(odir, "rt_oracle.cpp")
     out = os.path.join(odir, "_build", "librt_oracle.so")
-    if force or _newer(out, [src]):
-        os.makedirs(os.path.dirname(out), exist_ok=True)
-        _run([os.environ.get("CXX", "g++")] + CXX_FLAGS + [src, "-o", out])
+    lit = os.path.join(odir, "_build", "librt_oracle_reciprocal.so")
+    for target, extra in ((out, []), (lit, ["-DRT_ORACLE_RECIPROCAL_DIVISIONS"])):
+        if force or _newer(target, [src]):
+            os.makedirs(os.path.dirname(target), exist_ok=True)
+            _run([os.environ.get("CXX", "g++")] + CXX_FLAGS + extra + [src, "-o", target])
     return out
 
 

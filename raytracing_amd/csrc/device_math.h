@@ -5,9 +5,10 @@
 // the HLSL compiler and the GPU vendor.  This backend fixes one meaning — IEEE-754
 // binary32, round to nearest even, no fused multiply-add, correctly rounded division
 // and square root, subnormals kept — so that a CPU evaluation and the gfx950
-// evaluation of the same ray give the same bits.  normalize is v * (1 / sqrt(dot(v,v))), and a
-// division by a constant or per-frame value (pi, image size, sky size, the roulette sum) is a
-// multiplication by its correctly rounded reciprocal — the forms an HLSL compiler emits.  This file must be compiled with
+// evaluation of the same ray give the same bits.  Every `/` of the shader text is a true division
+// (uv / float2(width,height) :439, / -PI :407-408, specChance /= sum :395) and normalize is
+// v / sqrt(dot(v,v)); replacing them by multiplications with rounded reciprocals was measured to move
+// a few dozen primary-hit ids per 1080p frame, so it is not done.  This file must be compiled with
 // -ffp-contract=off; hipcc's default correctly rounded f32 divide/sqrt is relied on.
 #pragma once
 
@@ -28,9 +29,9 @@ __device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-__device__ __forceinline__ V3 normalize(V3 v) {
-    float r = 1.0f / __builtin_sqrtf(dot(v, v));
-    return {v.x * r, v.y * r, v.z * r};
+__device__ __forceinline__ V3 normalize(V3 v) {          // v / length(v): three true divisions
+    float l = __builtin_sqrtf(dot(v, v));
+    return {v.x / l, v.y / l, v.z / l};
 }
 __device__ __forceinline__ V3 reflect(V3 i, V3 n) { return i - (2.0f * dot(n, i)) * n; }
 __device__ __forceinline__ float fmin_(float a, float b) { return __builtin_fminf(a, b); }
@@ -51,7 +52,6 @@ __device__ __forceinline__ V3 mulDir(const float* m, V3 v) {
 }
 
 #define RT_PI 3.14159265f          /* RayTracingShader.compute:24 */
-#define RT_NEG_INV_PI -0.318309886f /* 1 / -RT_PI */
 #define RT_EPSILON 1e-8f           /* RayTracingShader.compute:27 */
 #define RT_INF __builtin_inff()
 

@@ -31,7 +31,6 @@ struct DevCounters {
 struct RenderArgs {
     rtamd_frame_cbuffer cb;
     int32_t width, height;
-    float invWidth, invHeight;            // 1.0f / width, 1.0f / height
     int32_t mode, spp, maxBounces;
     uint32_t seedHi, seedLo;
     int32_t sampleOffset;
@@ -73,9 +72,9 @@ __device__ __forceinline__ Ray cameraRay(const rtamd_frame_cbuffer& cb, float u,
     return makeRay(origin, d);
 }
 
-// uv = (id.xy + offset) / (w,h) * 2 - 1.  .compute:439  (invExtent = 1.0f / extent)
-__device__ __forceinline__ float pixelToNdc(int p, float offset, float invExtent) {
-    return ((float)p + offset) * invExtent * 2.0f - 1.0f;
+// uv = (id.xy + offset) / (w,h) * 2 - 1.  .compute:439
+__device__ __forceinline__ float pixelToNdc(int p, float offset, int extent) {
+    return ((float)p + offset) / (float)extent * 2.0f - 1.0f;
 }
 
 // Culled Möller–Trumbore.  .compute:198-231.  e1 = v1 - v0, e2 = v2 - v0.
@@ -126,8 +125,8 @@ __device__ __forceinline__ V3 sampleSky(const Sky& sky, float u, float v) {
 
 // Miss branch of Shade.  .compute:402-410
 __device__ __forceinline__ V3 shadeMiss(const Sky& sky, V3 dir) {
-    float theta = acosDecl(dir.y) * RT_NEG_INV_PI;
-    float phi = atan2Decl(dir.x, -dir.z) * RT_NEG_INV_PI * 0.5f;
+    float theta = acosDecl(dir.y) / -RT_PI;
+    float phi = atan2Decl(dir.x, -dir.z) / -RT_PI * 0.5f;
     return sampleSky(sky, phi, theta);
 }
 
@@ -159,9 +158,8 @@ __device__ __forceinline__ bool scatter(V3 albedoIn, V3 spec, V3 normal, V3 inDi
     float diffChance = energyOf(alb);
     float sum = specChance + diffChance;
     if (!(sum > 0.0f)) return false;
-    float rsum = 1.0f / sum;
-    specChance = specChance * rsum;
-    diffChance = diffChance * rsum;
+    specChance = specChance / sum;
+    diffChance = diffChance / sum;
     float roulette = rngDraw(key, 2u + 3u * bounce);
     if (roulette < specChance) {
         outDir = reflect(inDir, normal);

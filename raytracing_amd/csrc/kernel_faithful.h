@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64) void kFaithful(RefScene sc, Sky sky, RenderArgs
     if (inside) {
         size_t pix = (size_t)y * a.width + x;
         if (doPrimary && (a.mode == RTAMD_MODE_REF || a.outIds || a.outT)) {
-            Ray cam = cameraRay(a.cb, pixelToNdc(x, a.cb.PixelOffset[0], a.invWidth), pixelToNdc(y, a.cb.PixelOffset[1], a.invHeight));
+            Ray cam = cameraRay(a.cb, pixelToNdc(x, a.cb.PixelOffset[0], a.width), pixelToNdc(y, a.cb.PixelOffset[1], a.height));
             LocalCounters side = {0, 0, 0, 0, 0, 0, 0, 0};
             LocalCounters& use = a.mode == RTAMD_MODE_REF ? cnt : side;
             HitRec h = refIntersectTlas(sc, cam, blasStack, use);
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64) void kFaithful(RefScene sc, Sky sky, RenderArgs
                 uint32_t key = rngKey(a.seedHi, a.seedLo, (uint32_t)pix, (uint32_t)(a.sampleOffset + s));
                 float jx = a.cb.PixelOffset[0], jy = a.cb.PixelOffset[1];
                 if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
-                Ray ray = cameraRay(a.cb, pixelToNdc(x, jx, a.invWidth), pixelToNdc(y, jy, a.invHeight));
+                Ray ray = cameraRay(a.cb, pixelToNdc(x, jx, a.width), pixelToNdc(y, jy, a.height));
                 V3 L = v3(0, 0, 0), energy = v3(1, 1, 1);
                 for (int b = 0;; b++) {
                     HitRec h = refIntersectTlas(sc, ray, blasStack, cnt);

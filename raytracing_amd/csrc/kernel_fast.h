@@ -606,7 +606,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                     key = rngKey(a.seedHi, a.seedLo, (uint32_t)((size_t)py * a.width + px), (uint32_t)(a.sampleOffset + sample));
                     if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
                 }
-                const Ray cam = cameraRay(a.cb, pixelToNdc(px, jx, a.invWidth), pixelToNdc(py, jy, a.invHeight));
+                const Ray cam = cameraRay(a.cb, pixelToNdc(px, jx, a.width), pixelToNdc(py, jy, a.height));
                 nextO = cam.origin; nextD = cam.direction;
                 energy = v3(1, 1, 1); L = v3(0, 0, 0); bounce = 0;
                 pathActive = true;

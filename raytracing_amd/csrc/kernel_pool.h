@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                                     const uint32_t key = rngKey(a.seedHi, a.seedLo, pix, (uint32_t)(a.sampleOffset + b.sampleBase + smp));
                                     float jx = a.cb.PixelOffset[0], jy = a.cb.PixelOffset[1];
                                     if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
-                                    const Ray r = cameraRay(a.cb, pixelToNdc(x, jx, a.invWidth), pixelToNdc(y, jy, a.invHeight));
+                                    const Ray r = cameraRay(a.cb, pixelToNdc(x, jx, a.width), pixelToNdc(y, jy, a.height));
                                     if (rayDegenerate(r)) poolHandOver(a, pix);
                                     else {
                                         rec->r0 = make_float4(r.origin.x, r.origin.y, r.origin.z, r.direction.x);

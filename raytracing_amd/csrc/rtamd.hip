@@ -475,7 +475,6 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
     std::memset(&a, 0, sizeof(a));
     a.cb = *frame;
     a.width = width; a.height = height;
-    a.invWidth = 1.0f / (float)width; a.invHeight = 1.0f / (float)height;
     a.mode = e.mode; a.spp = e.mode == RTAMD_MODE_PT ? e.spp : 1; a.maxBounces = e.max_bounces;
     a.seedHi = (uint32_t)(e.seed >> 32); a.seedLo = (uint32_t)e.seed;
     a.sampleOffset = e.sample_offset;
