@@ -121,6 +121,14 @@ def render(buffers, frame, width, height, sky=None, mode=0, spp=1, max_bounces=8
     return dict(rgba=rgba, ids=ids, t=t, counters=counters, overflow=rc != 0)
 
 
+def last_max_entry_gap():
+    """Largest (box entry - hit distance) / hit distance over the accepted hits of the last render():
+    rounding only (a triangle lies inside its leaf-slot box); diagnostic for distance-culling kernels."""
+    f = lib().oracle_last_max_entry_gap
+    f.restype = C.c_float
+    return float(f())
+
+
 def bruteforce_primary(buffers, frame, width, height):
     sc = _scene(buffers, None)
     ids = np.zeros((height, width, 2), dtype=np.int32)

@@ -29,9 +29,10 @@ def lib():
     """Load librtamd.so (raises if it has not been built)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            raise RuntimeError(f"{_LIB_PATH} is missing: run `python -m raytracing_amd.build` (needs hipcc)")
-        L = C.CDLL(_LIB_PATH)
+        path = os.environ.get("RTAMD_LIB", _LIB_PATH)       # (experiments: another build of the same library)
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `python -m raytracing_amd.build` (needs hipcc)")
+        L = C.CDLL(path)
         L.rtamd_version.restype = C.c_char_p
         L.rtamd_last_error_string.restype = C.c_char_p
         L.rtamd_last_error_string.argtypes = [C.c_void_p]

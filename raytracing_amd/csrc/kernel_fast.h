@@ -24,7 +24,7 @@
 //     the closest hit so far, and a box's computed entry distance may exceed the computed hit
 //     distance of its own triangle by an ulp or two — whether that triangle is then tested
 //     depends on what was found before it.  Here boxes are culled against the closest hit times
-//     (1 + 2^-12), so such triangles are all tested, the closest one wins, and the segment is
+//     (1 + 2^-8), so such triangles are all tested, the closest one wins, and the segment is
 //     declared ambiguous when another triangle was hit closer than the entry distance of the
 //     winner's own boxes (slot box and instance box): only then could the reference have culled
 //     the winner.  Ambiguous pixels go to the reference-order kernel as well.
@@ -382,7 +382,9 @@ __device__ __forceinline__ float slabNear(float lo_x, float hi_x, float lo_y, fl
 }
 
 // Boxes are culled against the closest hit so far times this factor (see the file header).
-#define RT_CULL_RELAX 1.000244140625f   /* 1 + 2^-12 */
+#ifndef RT_CULL_RELAX
+#define RT_CULL_RELAX 1.00390625f   /* 1 + 2^-8 */
+#endif
 
 __device__ __forceinline__ void cswap(float& da, int32_t& ca, float& db, int32_t& cb) {
     bool sw = db < da;

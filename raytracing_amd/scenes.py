@@ -289,3 +289,57 @@ def random_soup(width=640, height=360, seed=0, meshes=4, tris_per_mesh=600, inst
     eye = np.array([np.cos(ang), rs.uniform(-0.3, 0.6), np.sin(ang)]) * world * rs.uniform(0.2, 1.4)
     frame = look_at_camera(tuple(eye), tuple(rs.uniform(-0.1, 0.1, 3) * world), float(rs.uniform(30, 80)), width, height)
     return buf, frame, procedural_sky()
+
+
+def sliver_scene(w, h, seed, coord, inst_scale, n_tris=400, instances=12, distance=8.0):
+    """Stress scene for the production kernel's distance culling: slivers (aspect 1e4 .. 3e5) and a few
+    wide triangles stored `coord` (1e3 .. 1e5) away from their mesh's origin, under rotated, mirrored,
+    non-uniformly scaled instances of overall scale `inst_scale` (1e-3 .. 1e3) that bring them back to
+    the world origin; odd seeds look along the horizon (grazing rays), even seeds straight down an
+    axis.  At these coordinates binary32 cancellation makes a box's computed entry distance and its
+    own triangle's computed hit distance disagree by far more than an ulp."""
+    rs = np.random.RandomState(seed)
+    sys_ = H.BuildAccelerateStructureSystem(tlas_tree=int(rs.randint(0, 2)))
+    blas = []
+    for m in range(3):
+        base = rs.uniform(-1, 1, size=(n_tris, 3)) * 2.0 + rs.choice([-1, 1], size=3) * coord
+        long_dir = rs.normal(size=(n_tris, 3))
+        long_dir /= np.linalg.norm(long_dir, axis=1, keepdims=True)
+        short_dir = np.cross(long_dir, rs.normal(size=(n_tris, 3)))
+        short_dir /= np.linalg.norm(short_dir, axis=1, keepdims=True)
+        L = rs.uniform(1.0, 4.0, size=(n_tris, 1))
+        aspect = 10.0 ** rs.uniform(4.0, 5.5, size=(n_tris, 1))
+        p0, p1, p2 = base, base + long_dir * L, base + long_dir * L * 0.5 + short_dir * (L / aspect)
+        pos = np.concatenate([p0, p1, p2]).astype(np.float32)
+        idx = np.stack([np.arange(n_tris), np.arange(n_tris) + n_tris, np.arange(n_tris) + 2 * n_tris], 1).astype(np.int32)
+        # a few wide triangles so that something is hit behind the slivers
+        nrm = np.cross(p1 - p0, p2 - p0)
+        nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)
+        nv = np.concatenate([nrm, nrm, nrm]).astype(np.float32)
+        big0 = base[:40]
+        bp = np.concatenate([big0, big0 + rs.normal(size=(40, 3)) * 1.5, big0 + rs.normal(size=(40, 3)) * 1.5]).astype(np.float32)
+        bi = np.stack([np.arange(40), np.arange(40) + 40, np.arange(40) + 80], 1).astype(np.int32) + len(pos)
+        bn = np.tile(np.array([[0, 1, 0]], np.float32), (120, 1))
+        mesh = H.Mesh(np.concatenate([pos, bp]), np.concatenate([nv, bn]), np.concatenate([idx, bi]))
+        blas.append((sys_.BakeBLAS(mesh, int(rs.randint(0, 2))), base.mean(0)))
+    for i in range(instances):
+        b, c_local = blas[i % 3]
+        q = H.quat_axis_angle(rs.normal(size=3) + 1e-3, float(rs.uniform(0, 360)))
+        s = inst_scale * (10.0 ** rs.uniform(-0.3, 0.3, size=3))
+        if rs.rand() < 0.3:
+            s[int(rs.randint(0, 3))] *= -1
+        # place the instance so that its mesh (centred at c_local in local space) lands near the world origin
+        m0 = H.trs((0, 0, 0), q, tuple(s)).reshape(4, 4).T
+        t = rs.uniform(-1, 1, size=3) * 3.0 * inst_scale - (m0[:3, :3] @ c_local)
+        kind = rs.rand()
+        mat = dict(albedo=tuple(rs.uniform(0.2, 0.9, 3)), specular=(0.04, 0.04, 0.04)) if kind < 0.6 else (
+            dict(albedo=(0, 0, 0), specular=tuple(rs.uniform(0.5, 1.0, 3))) if kind < 0.85 else dict(albedo=(0, 0, 0), specular=(0, 0, 0), emission=(2, 2, 2)))
+        sys_.AddEntity(b, H.trs(tuple(t), q, tuple(s)), **mat)
+    buf = sys_.OnUpdate()
+    sys_.close()
+    R = distance * inst_scale
+    ang = rs.uniform(0, 2 * np.pi)
+    # near-axis and grazing views
+    eye = np.array([np.cos(ang) * R, rs.uniform(-0.05, 0.05) * R, np.sin(ang) * R]) if seed % 2 else np.array([R * 1e-4, R, R * 1e-4])
+    frame = look_at_camera(tuple(eye), (0.0, 0.0, 0.0), float(rs.uniform(20, 60)), w, h)
+    return buf, frame, procedural_sky()

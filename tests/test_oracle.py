@@ -168,3 +168,18 @@ def test_division_reading_is_counted(oracle, capsys):
     with capsys.disabled():
         for r in rows:
             print("\n[division reading] %s %dx%d: primary ids that move %d, t values %d, 8-bit REF pixels %d" % r, end="")
+
+
+def test_box_entry_never_far_behind_the_hit_distance(oracle):
+    """A triangle lies inside its leaf-slot box, so the box's entry distance can exceed the triangle's
+    hit distance only by rounding.  The production kernel's distance culling allows 2^-8 of relative
+    slack for that; the oracle measures the largest excess over all accepted hits of a render.  On
+    ordinary scenes it is a few ulps; on the sliver stress scene up to 1.4 x 2^-12."""
+    from raytracing_amd import scenes
+    for make, limit in ((lambda: scenes.random_spheres(240, 135), 2.0 ** -18), (lambda: scenes.reference_scene(None, 240, 135), 2.0 ** -18),
+                        (lambda: scenes.sliver_scene(160, 90, 1, 1e4, 1.0, distance=3.0), 2.0 ** -10)):
+        buf, frame, sky = make()
+        h, w = (135, 240) if limit < 1e-5 else (90, 160)
+        oracle.render(buf, frame, w, h, sky=sky, mode=1, spp=2, max_bounces=6, seed=1, nthreads=8)
+        gap = oracle.last_max_entry_gap()
+        assert 0.0 <= gap < limit, gap
