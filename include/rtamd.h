@@ -90,8 +90,20 @@ enum {
     RTAMD_FLAG_REFERENCE_ORDER = 1 << 2, /* traverse in the reference's exact node order on the reference's own node layout */
     RTAMD_FLAG_OUTPUT_SUM      = 1 << 3, /* PT: write the un-normalised sample sum (for cross-GPU sample sharding) */
     RTAMD_FLAG_COUNTERS        = 1 << 4, /* also fill the work counters (forces REFERENCE_ORDER so the counts are the reference's) */
-    RTAMD_FLAG_SHARD_SAMPLES   = 1 << 5  /* PT on a context over several GPUs: split the samples, not the tiles, over the GPUs */
+    RTAMD_FLAG_SHARD_SAMPLES   = 1 << 5, /* PT on a context over several GPUs: split the samples, not the tiles, over the GPUs */
+    RTAMD_FLAG_DIELECTRICS     = 1 << 6  /* PT: objects whose specular[3] is RTAMD_MATERIAL_DIELECTRIC transmit light (see below) */
 };
+
+/* Dielectric extension (no counterpart in the reference: RayTraceMaterial.cs:12-17 has no
+ * transmission term and Trisection culls back faces, RayTracingShader.compute:205).  It uses
+ * the fourth components of albedo and specular, which the reference declares (float4) and the
+ * shader never reads (.xyz only, :336-338): with RTAMD_FLAG_DIELECTRICS set, an object whose
+ * specular[3] == RTAMD_MATERIAL_DIELECTRIC is glass with refractive index albedo[3] and
+ * transmission tint albedo[0..2].  A path that refracted into glass tests triangles from both
+ * sides until it refracts out again; at a glass surface Schlick's Fresnel term chooses between
+ * mirror reflection and refraction with the segment's roulette draw.  Without the flag the
+ * fourth components are ignored, as in the reference. */
+#define RTAMD_MATERIAL_DIELECTRIC 2.0f
 
 /* Work counters, summed over every ray segment of one render call. */
 typedef struct rtamd_counters {

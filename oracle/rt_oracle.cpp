@@ -34,6 +34,7 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -85,7 +86,7 @@ struct Params {
     int32_t sample_offset;
     int32_t tile_x, tile_y, tile_w, tile_h;
     int32_t shard_rank, shard_count;
-    uint32_t flags;          // 1 accumulate(ignored here) 2 no-jitter 8 output-sum
+    uint32_t flags;          // 1 accumulate(ignored here) 2 no-jitter 8 output-sum 64 dielectrics
     int32_t nthreads;
 };
 
@@ -262,22 +263,35 @@ static inline Ray CreateCameraRay(const FrameCBuffer& cb, float u, float v) { //
 struct RayHit {                                               // .compute:160-168
     float3 position; float distance; float3 normal, albedo, specular, emission;
     int32_t object, triangle;  // added: identity of the accepted hit
+    // added for the dielectric extension: the unused fourth components of albedo / specular
+    // (RayTraceMaterial.cs:12-17 declares float4s, the shader reads .xyz only) and whether the
+    // triangle was hit from behind (only rays inside a dielectric test back faces)
+    float albedoW, specularW;
+    bool backface;
 };
 static inline RayHit CreateRayHit() {                         // .compute:169-179
     RayHit h;
     h.position = f3(0, 0, 0); h.distance = INF; h.normal = f3(0, 0, 0);
     h.albedo = f3(0, 0, 0); h.specular = f3(0, 0, 0); h.emission = f3(0, 0, 0);
     h.object = -1; h.triangle = -1;
+    h.albedoW = 0.0f; h.specularW = 0.0f; h.backface = false;
     return h;
 }
 
 // Möller–Trumbore with back-face culling.  .compute:198-231
-static inline bool Trisection(const Ray& ray, float3 v0, float3 v1, float3 v2, float& T, float& U, float& V) {
+// twoSided (dielectric extension, a ray travelling inside glass): the determinant may have either
+// sign, only |det| < EPSILON is rejected; `back` reports det < 0.  For det >= EPSILON the
+// arithmetic is the reference's, operation for operation.
+static inline bool Trisection(const Ray& ray, float3 v0, float3 v1, float3 v2, float& T, float& U, float& V,
+                              bool twoSided = false, bool* back = nullptr) {
     float3 v0v1 = v1 - v0;
     float3 v0v2 = v2 - v0;
     float3 pvec = cross(ray.direction, v0v2);
     float det = dot(v0v1, pvec);
-    if (det < EPSILON) return false;
+    if (det < EPSILON) {
+        if (!twoSided || det > -EPSILON) return false;
+    }
+    if (back) *back = det < 0.0f;
     float inv_det = 1.0f / det;
     float3 tvec = ray.origin - v0;
     float u = dot(tvec, pvec) * inv_det;
@@ -313,13 +327,31 @@ static const int MAX_BLAS_STACK = 64 * 4;   // MAX_BLAS_STACK_INT4 = 64  (.compu
 static const int MAX_TLAS_STACK = 8 * 4;    // MAX_TLAS_STACK_INT4 = 8   (.compute:94)
 static const int ORACLE_STACK = 4096;       // the oracle keeps going past the shader's limit and reports it
 
+// Diagnostic, not part of the reference: the largest (entry distance of the accepted triangle's own
+// leaf-slot box - its hit distance) / hit distance seen by any accepted hit of the last render.  In
+// exact arithmetic it is <= 0 (a triangle lies inside its box); what is left is rounding.  A kernel
+// that culls boxes by distance with a relative slack must keep the slack above this.
+static std::mutex g_gapLock;
+static float g_maxEntryGap = 0.0f;
+
+static inline float slotNear(const Node& n, int i, const Ray& ray) {
+    float nearXt = (n.Lx[i] - ray.origin.x) * ray.invDir.x, farXt = (n.Hx[i] - ray.origin.x) * ray.invDir.x;
+    float nearYt = (n.Ly[i] - ray.origin.y) * ray.invDir.y, farYt = (n.Hy[i] - ray.origin.y) * ray.invDir.y;
+    float nearZt = (n.Lz[i] - ray.origin.z) * ray.invDir.z, farZt = (n.Hz[i] - ray.origin.z) * ray.invDir.z;
+    return ofmax(ofmax(ofmax(ofmin(nearXt, farXt), ofmin(nearYt, farYt)), ofmin(nearZt, farZt)), 0.0f);
+}
+
 struct Tracer {
     const Scene& sc;
     Counters cnt;
+    float maxEntryGap = 0.0f;
     explicit Tracer(const Scene& s) : sc(s) { std::memset(&cnt, 0, sizeof(cnt)); }
+    ~Tracer() {
+        if (maxEntryGap > 0.0f) { std::lock_guard<std::mutex> hold(g_gapLock); if (maxEntryGap > g_maxEntryGap) g_maxEntryGap = maxEntryGap; }
+    }
 
     // .compute:277-346
-    void IntersectBLAS(const Ray& ray, int index, RayHit& bestHit) {
+    void IntersectBLAS(const Ray& ray, int index, RayHit& bestHit, bool twoSided = false) {
         const ObjectProperty& property = sc.objects[index];
         int blasIndex = property.BLASIndex;
         int blasOffset = sc.blasOffsets[blasIndex];
@@ -361,11 +393,13 @@ struct Tracer {
                         const Vertex& v2 = sc.verts[aTriangle.z + vertexOffset];
                         cnt.tris++;
                         float t, u, v;
+                        bool back = false;
                         if (Trisection(localRay, f3(v0.position[0], v0.position[1], v0.position[2]),
                                        f3(v1.position[0], v1.position[1], v1.position[2]),
-                                       f3(v2.position[0], v2.position[1], v2.position[2]), t, u, v)) {
+                                       f3(v2.position[0], v2.position[1], v2.position[2]), t, u, v, twoSided, &back)) {
                             if (t > 0 && t < bestHit.distance) {
                                 cnt.hits++;
+                                { const float gap = (slotNear(node, i, localRay) - t) / t; if (gap > maxEntryGap) maxEntryGap = gap; }
                                 bestHit.distance = t;
                                 bestHit.position = mulPoint(localToWorld, localRay.origin + t * localRay.direction);
                                 float w = 1 - u - v;
@@ -379,6 +413,8 @@ struct Tracer {
                                 bestHit.emission = f3(property.emission[0], property.emission[1], property.emission[2]);
                                 bestHit.object = index;
                                 bestHit.triangle = triangleIndex;
+                                bestHit.albedoW = property.albedo[3]; bestHit.specularW = property.specular[3];
+                                bestHit.backface = back;
                             }
                         }
                     }
@@ -388,7 +424,7 @@ struct Tracer {
     }
 
     // .compute:348-384
-    RayHit IntersectTLAS(const Ray& ray) {
+    RayHit IntersectTLAS(const Ray& ray, bool twoSided = false) {
         RayHit bestHit = CreateRayHit();
         cnt.rays++;
         int stack[ORACLE_STACK / 8];
@@ -413,7 +449,7 @@ struct Tracer {
                         if (top >= cap) top = cap - 1;
                     }
                 } else {
-                    if (node.Data[i] != -1) IntersectBLAS(ray, node.Data[i], bestHit);
+                    if (node.Data[i] != -1) IntersectBLAS(ray, node.Data[i], bestHit, twoSided);
                 }
             }
         } while (top > 0);
@@ -506,17 +542,60 @@ static inline float3 SampleHemisphere(float3 normal, float u1, float u2) {
 // PT mode: the path loop the shader's unused code sketches — specular / diffuse roulette
 // (.compute:391-399 and the tutorial it cites), emission return (:400), sky on miss
 // (:405-409), origin offset n*0.001 (:397).
-static inline float3 tracePath(Tracer& tr, Ray ray, uint32_t key, int maxBounces) {
+//
+// Dielectric extension (`dielectrics`, flag 64; nothing in the reference transmits light: its material
+// has no such term, RayTraceMaterial.cs:12-17, and its triangle test culls back faces, :205): an
+// object whose specular.w is 2 is glass with refractive index albedo.w and transmission tint
+// albedo.xyz.  A ray that refracted into glass is `inside` until it refracts out again, and only
+// such rays test triangles from both sides; a triangle hit from behind is shaded with its normal
+// flipped.  At a glass surface: Schlick's Fresnel term F (1 on total internal reflection), the
+// segment's roulette draw picks mirror reflection (probability F, weight 1, origin offset along the
+// normal) or refraction (weight tint, direction by Snell's law, renormalised, origin offset against
+// the normal).
+static const float DIELECTRIC_TAG = 2.0f;
+
+static inline float3 tracePath(Tracer& tr, Ray ray, uint32_t key, int maxBounces, bool dielectrics = false) {
     float3 L = f3(0, 0, 0);
     float3 energy = f3(1, 1, 1);
+    bool inside = false;
     for (int b = 0;; b++) {
-        RayHit hit = tr.IntersectTLAS(ray);
+        RayHit hit = tr.IntersectTLAS(ray, inside);
         if (!(hit.distance < INF)) {
             L = L + energy * shadeMiss(tr.sc, ray.direction);
             break;
         }
+        if (hit.backface) hit.normal = f3(-hit.normal.x, -hit.normal.y, -hit.normal.z);
         L = L + energy * hit.emission;
         if (b >= maxBounces) break;
+        if (dielectrics && hit.specularW == DIELECTRIC_TAG) {
+            const float ior = hit.albedoW;
+            const float eta = hit.backface ? ior : 1.0f / ior;
+            const float cosi = saturate(-dot(ray.direction, hit.normal));
+            float r0 = (1.0f - ior) / (1.0f + ior);
+            r0 = r0 * r0;
+            const float sin2t = (eta * eta) * (1.0f - cosi * cosi);
+            float F = 1.0f;
+            if (!(sin2t > 1.0f)) {
+                const float m = 1.0f - cosi;
+                const float m2 = m * m;
+                F = r0 + (1.0f - r0) * ((m2 * m2) * m);
+            }
+            const float roulette = rngDraw(key, 2u + 3u * (uint32_t)b);
+            float3 dir, origin;
+            if (roulette < F) {
+                dir = reflect(ray.direction, hit.normal);
+                origin = hit.position + hit.normal * 0.001f;
+            } else {
+                const float cost = std::sqrt(ofmax(0.0f, 1.0f - sin2t));
+                dir = normalize((eta * ray.direction) + ((eta * cosi - cost) * hit.normal));
+                origin = hit.position + hit.normal * -0.001f;
+                energy = energy * hit.albedo;
+                inside = !hit.backface;
+            }
+            if (!(energy.x > 0.0f || energy.y > 0.0f || energy.z > 0.0f)) break;
+            ray = CreateRay(origin, dir);
+            continue;
+        }
         float3 spec = hit.specular;
         float3 alb = f3(ofmin(1.0f - spec.x, hit.albedo.x), ofmin(1.0f - spec.y, hit.albedo.y),
                         ofmin(1.0f - spec.z, hit.albedo.z));
@@ -596,7 +675,7 @@ static void renderRows(const Scene& sc, const FrameCBuffer& cb, const Params& p,
                     float u = pixelToNdc(x, jx, width);
                     float v = pixelToNdc(y, jy, height);
                     Ray cam = CreateCameraRay(cb, u, v);
-                    sum = sum + tracePath(tr, cam, key, p.max_bounces);
+                    sum = sum + tracePath(tr, cam, key, p.max_bounces, (p.flags & 64u) != 0);
                 }
                 if (rgba) {
                     if (p.flags & 8u) {
@@ -627,6 +706,7 @@ int oracle_render(const Scene* sc, const FrameCBuffer* cb, const Params* p, int 
                   float* rgba, int32_t* ids, float* tout, Counters* counters) {
     int nt = p->nthreads > 0 ? p->nthreads : 1;
     if (nt > height) nt = height;
+    { std::lock_guard<std::mutex> hold(g_gapLock); g_maxEntryGap = 0.0f; }
     std::vector<Counters> cnts(nt);
     if (nt == 1) {
         renderRows(*sc, *cb, *p, width, height, 0, height, rgba, ids, tout, &cnts[0]);
@@ -660,6 +740,12 @@ int oracle_render(const Scene* sc, const FrameCBuffer* cb, const Params* p, int 
     }
     if (counters) *counters = tot;
     return tot.overflow ? 1 : 0;
+}
+
+// See g_maxEntryGap: of the last oracle_render call (0 when no accepted hit had a box entry behind it).
+float oracle_last_max_entry_gap(void) {
+    std::lock_guard<std::mutex> hold(g_gapLock);
+    return g_maxEntryGap;
 }
 
 // Closest front-facing hit of the un-jittered primary ray by testing EVERY triangle of

@@ -78,10 +78,16 @@ __device__ __forceinline__ float pixelToNdc(int p, float offset, int extent) {
 }
 
 // Culled Möller–Trumbore.  .compute:198-231.  e1 = v1 - v0, e2 = v2 - v0.
-__device__ __forceinline__ bool trisect(V3 org, V3 dir, V3 v0, V3 e1, V3 e2, float& T, float& U, float& V) {
+// twoSided (a ray travelling inside a dielectric, extension): either sign of the determinant is
+// accepted, only |det| < EPSILON is rejected, and `back` reports det < 0; for det >= EPSILON the
+// operations are the reference's.
+__device__ __forceinline__ bool trisect(V3 org, V3 dir, V3 v0, V3 e1, V3 e2, float& T, float& U, float& V, bool twoSided, bool& back) {
     V3 pvec = cross(dir, e2);
     float det = dot(e1, pvec);
-    if (det < RT_EPSILON) return false;
+    if (det < RT_EPSILON) {
+        if (!twoSided || det > -RT_EPSILON) return false;
+    }
+    back = twoSided && det < 0.0f;
     float inv_det = 1.0f / det;
     V3 tvec = org - v0;
     float u = dot(tvec, pvec) * inv_det;
@@ -171,6 +177,46 @@ __device__ __forceinline__ bool scatter(V3 albedoIn, V3 spec, V3 normal, V3 inDi
         energy = energy * ((((1.0f / diffChance) * 2.0f) * alb) * saturate(dot(normal, outDir)));
     }
     return energy.x > 0.0f || energy.y > 0.0f || energy.z > 0.0f;
+}
+
+// What the path tracer needs of a hit surface.  normal already points against the side that was hit.
+struct Surf { V3 position, normal, albedo, specular, emission; float albedoW, specularW; bool back; int32_t object, triangle; };
+
+// Next segment of a path at surface `s`: false when the path ends.  DIEL: glass (specular.w ==
+// RTAMD_MATERIAL_DIELECTRIC, index of refraction albedo.w, tint albedo.xyz) reflects with Schlick's
+// Fresnel probability and refracts otherwise; `inside` follows the path into and out of the glass.
+template <bool DIEL>
+__device__ __forceinline__ bool scatterSurface(const Surf& s, V3 inDir, uint32_t key, uint32_t bounce, V3& energy, V3& outOrigin, V3& outDir,
+                                               bool& inside) {
+    if (DIEL && s.specularW == RTAMD_MATERIAL_DIELECTRIC) {
+        const float ior = s.albedoW;
+        const float eta = s.back ? ior : 1.0f / ior;
+        const float cosi = saturate(-dot(inDir, s.normal));
+        float r0 = (1.0f - ior) / (1.0f + ior);
+        r0 = r0 * r0;
+        const float sin2t = (eta * eta) * (1.0f - cosi * cosi);
+        float F = 1.0f;
+        if (!(sin2t > 1.0f)) {
+            const float m = 1.0f - cosi;
+            const float m2 = m * m;
+            F = r0 + (1.0f - r0) * ((m2 * m2) * m);
+        }
+        const float roulette = rngDraw(key, 2u + 3u * bounce);
+        if (roulette < F) {
+            outDir = reflect(inDir, s.normal);
+            outOrigin = s.position + s.normal * 0.001f;
+        } else {
+            const float cost = __builtin_sqrtf(fmax_(0.0f, 1.0f - sin2t));
+            outDir = normalize((eta * inDir) + ((eta * cosi - cost) * s.normal));
+            outOrigin = s.position + s.normal * -0.001f;
+            energy = energy * s.albedo;
+            inside = !s.back;
+        }
+        return energy.x > 0.0f || energy.y > 0.0f || energy.z > 0.0f;
+    }
+    if (!scatter(s.albedo, s.specular, s.normal, inDir, key, bounce, energy, outDir)) return false;
+    outOrigin = s.position + s.normal * 0.001f;
+    return true;
 }
 
 __device__ __forceinline__ bool pixelSelected(const RenderArgs& a, int x, int y) {

@@ -15,6 +15,7 @@ namespace rt {
 struct HitRec {
     float t, u, v;
     int32_t object, triangle;
+    bool back;           // hit from behind (only rays inside a dielectric test both sides)
 };
 
 struct LocalCounters {
@@ -45,7 +46,7 @@ __device__ __forceinline__ bool refSlab(const rtamd_node& n, int i, const Ray& r
 // The four-box mask is evaluated once per node with the distance at that time (:298);
 // hits accepted while walking a leaf's slots do not re-filter its later slots.
 __device__ __forceinline__ void refIntersectBlas(const RefScene& sc, const Ray& ray, int index, HitRec& best,
-                                                 int32_t* stack, LocalCounters& cnt) {
+                                                 int32_t* stack, LocalCounters& cnt, bool twoSided) {
     const rtamd_object_property& prop = sc.objects[index];
     int blasIndex = prop.BLASIndex;
     int blasOffset = sc.blasOffsets[blasIndex];
@@ -87,11 +88,12 @@ __device__ __forceinline__ void refIntersectBlas(const RefScene& sc, const Ray& 
                     V3 v2 = v3(c.position[0], c.position[1], c.position[2]);
                     cnt.tris++;
                     float t, u, v;
-                    if (trisect(localRay.origin, localRay.direction, v0, v1 - v0, v2 - v0, t, u, v)) {
+                    bool back;
+                    if (trisect(localRay.origin, localRay.direction, v0, v1 - v0, v2 - v0, t, u, v, twoSided, back)) {
                         if (t > 0 && t < best.t) {
                             cnt.hits++;
                             best.t = t; best.u = u; best.v = v;
-                            best.object = index; best.triangle = triangleIndex;
+                            best.object = index; best.triangle = triangleIndex; best.back = back;
                         }
                     }
                 }
@@ -103,9 +105,9 @@ __device__ __forceinline__ void refIntersectBlas(const RefScene& sc, const Ray& 
 // IntersectTLAS, .compute:348-384.  As in the BLAS loop the mask is computed once per
 // node (:360), before any BLAS visit of that node can shrink the distance.
 __device__ __forceinline__ HitRec refIntersectTlas(const RefScene& sc, const Ray& ray, int32_t* blasStack,
-                                                   LocalCounters& cnt) {
+                                                   LocalCounters& cnt, bool twoSided = false) {
     HitRec best;
-    best.t = RT_INF; best.u = 0; best.v = 0; best.object = -1; best.triangle = -1;
+    best.t = RT_INF; best.u = 0; best.v = 0; best.object = -1; best.triangle = -1; best.back = false;
     cnt.rays++;
     int32_t stack[kRefTlasStack];
     int top = 0;
@@ -129,18 +131,17 @@ __device__ __forceinline__ HitRec refIntersectTlas(const RefScene& sc, const Ray
                     if ((uint32_t)top > cnt.maxTlas) cnt.maxTlas = top;
                 }
             } else if (data != -1) {
-                refIntersectBlas(sc, ray, data, best, blasStack, cnt);
+                refIntersectBlas(sc, ray, data, best, blasStack, cnt, twoSided);
             }
         }
     } while (top > 0);
     return best;
 }
 
-struct Surface { V3 position, normal, albedo, specular, emission; };
 
 // What IntersectBLAS stores on an accepted hit (.compute:329-339), evaluated once for
 // the hit that survived.
-__device__ __forceinline__ Surface refResolve(const RefScene& sc, const Ray& ray, const HitRec& h) {
+__device__ __forceinline__ Surf refResolve(const RefScene& sc, const Ray& ray, const HitRec& h) {
     const rtamd_object_property& prop = sc.objects[h.object];
     int blasIndex = prop.BLASIndex;
     int triangleOffset = sc.triOffsets[blasIndex];
@@ -150,7 +151,7 @@ __device__ __forceinline__ Surface refResolve(const RefScene& sc, const Ray& ray
     const rtamd_vertex& a = sc.verts[tri.x + vertexOffset];
     const rtamd_vertex& b = sc.verts[tri.y + vertexOffset];
     const rtamd_vertex& c = sc.verts[tri.z + vertexOffset];
-    Surface s;
+    Surf s;
     s.position = mulPoint(prop.LocalToWorld, localRay.origin + h.t * localRay.direction);
     float w = 1 - h.u - h.v;
     V3 n0 = v3(a.normal[0], a.normal[1], a.normal[2]);
@@ -161,6 +162,10 @@ __device__ __forceinline__ Surface refResolve(const RefScene& sc, const Ray& ray
     s.albedo = v3(prop.albedo[0], prop.albedo[1], prop.albedo[2]);
     s.specular = v3(prop.specular[0], prop.specular[1], prop.specular[2]);
     s.emission = v3(prop.emission[0], prop.emission[1], prop.emission[2]);
+    s.albedoW = prop.albedo[3]; s.specularW = prop.specular[3];
+    s.back = h.back;
+    if (h.back) s.normal = v3(-s.normal.x, -s.normal.y, -s.normal.z);
+    s.object = h.object; s.triangle = h.triangle;
     return s;
 }
 
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(64) void kFaithful(RefScene sc, Sky sky, RenderArgs
                 // contributes its emission and a miss the sky along the mirrored direction.
                 float4 px = make_float4(0, 0, 0, 0);
                 if (h.t < RT_INF) {
-                    Surface s = refResolve(sc, cam, h);
+                    Surf s = refResolve(sc, cam, h);
                     Ray ray = makeRay(s.position, reflect(cam.direction, s.normal));
                     HitRec h2 = refIntersectTlas(sc, ray, blasStack, cnt);
                     V3 shade;
@@ -243,15 +248,19 @@ __global__ __launch_bounds__(64) void kFaithful(RefScene sc, Sky sky, RenderArgs
                 if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
                 Ray ray = cameraRay(a.cb, pixelToNdc(x, jx, a.width), pixelToNdc(y, jy, a.height));
                 V3 L = v3(0, 0, 0), energy = v3(1, 1, 1);
+                const bool dielectrics = (a.flags & RTAMD_FLAG_DIELECTRICS) != 0;
+                bool insideGlass = false;
                 for (int b = 0;; b++) {
-                    HitRec h = refIntersectTlas(sc, ray, blasStack, cnt);
+                    HitRec h = refIntersectTlas(sc, ray, blasStack, cnt, insideGlass);
                     if (!(h.t < RT_INF)) { L = L + energy * shadeMiss(sky, ray.direction); break; }
-                    Surface sf = refResolve(sc, ray, h);
+                    Surf sf = refResolve(sc, ray, h);
                     L = L + energy * sf.emission;
                     if (b >= a.maxBounces) break;
-                    V3 dir;
-                    if (!scatter(sf.albedo, sf.specular, sf.normal, ray.direction, key, (uint32_t)b, energy, dir)) break;
-                    ray = makeRay(sf.position + sf.normal * 0.001f, dir);
+                    V3 org, dir;
+                    const bool goOn = dielectrics ? scatterSurface<true>(sf, ray.direction, key, (uint32_t)b, energy, org, dir, insideGlass)
+                                                  : scatterSurface<false>(sf, ray.direction, key, (uint32_t)b, energy, org, dir, insideGlass);
+                    if (!goOn) break;
+                    ray = makeRay(org, dir);
                 }
                 sum = sum + L;
             }

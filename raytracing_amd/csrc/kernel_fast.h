@@ -330,8 +330,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct FastHit {
     float t, u, v;
-    int32_t inst, tri;   // instance rank, triangle rank (positions in the reference's visiting order)
+    int32_t inst, tri;   // instance rank, triangle rank (positions in the reference's visiting order); tri | kBackFaceBit when hit from behind
 };
+constexpr int32_t kBackFaceBit = 1 << 30;   // (triangle ranks stay below 2^28)
 
 // mul(M, float4(v,1)).xyz and mul(M, float4(v,0)).xyz for a matrix stored as three rows.
 __device__ __forceinline__ V3 rowsPoint(float4 r0, float4 r1, float4 r2, V3 v) {
@@ -399,8 +400,6 @@ __device__ __forceinline__ bool rayDegenerate(const Ray& r) {
     return !(__builtin_fabsf(r.invDir.x) < RT_INF) || !(__builtin_fabsf(r.invDir.y) < RT_INF) || !(__builtin_fabsf(r.invDir.z) < RT_INF);
 }
 
-struct Surf { V3 position, normal, albedo, specular, emission; int32_t object, triangle; };
-
 // Position, shading normal and material of the closest hit (.compute:329-339).
 __device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world, const FastHit& h) {
     const FInst fi = sc.inst[h.inst];
@@ -408,7 +407,8 @@ __device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world
     Ray local = makeRay(rowsPoint(fi.r0, fi.r1, fi.r2, world.origin), rowsDir(fi.r0, fi.r1, fi.r2, world.direction));
     Surf s;
     s.position = rowsPoint(fs.r0, fs.r1, fs.r2, local.origin + h.t * local.direction);
-    const FNrm g = sc.nrms[h.tri];
+    const int32_t tri = h.tri & ~kBackFaceBit;
+    const FNrm g = sc.nrms[tri];
     V3 n0 = v3(g.a.x, g.a.y, g.a.z), n1 = v3(g.a.w, g.b.x, g.b.y), n2 = v3(g.b.z, g.b.w, g.c.x);
     float w = 1 - h.u - h.v;
     V3 nl = ((h.u * n1) + (h.v * n2)) + (w * n0);
@@ -416,8 +416,11 @@ __device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world
     s.albedo = v3(fs.albedo.x, fs.albedo.y, fs.albedo.z);
     s.specular = v3(fs.specular.x, fs.specular.y, fs.specular.z);
     s.emission = v3(fs.emission.x, fs.emission.y, fs.emission.z);
+    s.albedoW = fs.albedo.w; s.specularW = fs.specular.w;
+    s.back = (h.tri & kBackFaceBit) != 0;
+    if (s.back) s.normal = v3(-s.normal.x, -s.normal.y, -s.normal.z);
     s.object = fi.object;
-    s.triangle = sc.triOrig[h.tri];
+    s.triangle = sc.triOrig[tri];
     return s;
 }
 
@@ -438,7 +441,9 @@ __device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world
 // reference-order kernel, which the host runs over that list afterwards.
 // STATS = true builds a diagnostic variant that also counts, per phase, how often the wave
 // executed it and with how many active lanes (written to `stats`, 16 counters).
-template <int MODE, bool STATS>
+// DIEL = true (PT mode with RTAMD_FLAG_DIELECTRICS): glass objects refract; a path inside glass tests
+// triangles from both sides.
+template <int MODE, bool STATS, bool DIEL = false>
 __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene sc, Sky sky, RenderArgs a, int refillBelow, int nodeMin, int leafGroupMin,
                                                        int stackLimit, unsigned long long* stats) {
     unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -475,6 +480,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
     uint32_t key = 0;
     int bounce = 0;
     V3 energy = v3(1, 1, 1), L = v3(0, 0, 0);
+    bool insideGlass = false;     // DIEL: the path is travelling inside a dielectric
     // traversal state
     bool trav = false;
     Ray world = makeRay(v3(0, 0, 0), v3(0, 0, 1));
@@ -524,9 +530,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                     Surf s = resolveHit(sc, world, best);
                     if (MODE == kModePt) {
                         L = L + energy * s.emission;
-                        V3 dir;
-                        if (bounce < a.maxBounces && scatter(s.albedo, s.specular, s.normal, world.direction, key, (uint32_t)bounce, energy, dir)) {
-                            nextO = s.position + s.normal * 0.001f; nextD = dir;
+                        V3 org, dir;
+                        if (bounce < a.maxBounces && scatterSurface<DIEL>(s, world.direction, key, (uint32_t)bounce, energy, org, dir, insideGlass)) {
+                            nextO = org; nextD = dir;
                             bounce++;
                             haveRay = true;
                         }
@@ -611,6 +617,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                 const Ray cam = cameraRay(a.cb, pixelToNdc(px, jx, a.width), pixelToNdc(py, jy, a.height));
                 nextO = cam.origin; nextD = cam.direction;
                 energy = v3(1, 1, 1); L = v3(0, 0, 0); bounce = 0;
+                insideGlass = false;
                 pathActive = true;
                 haveRay = true;
             }
@@ -629,7 +636,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
 
         // ------------------------------------------------ phase B: traversal
 #define RT_CAN_REFILL (!trav && !(noMoreWork && !pixelActive && !pathActive))
+#define RT_TWO_SIDED (DIEL && insideGlass)
 #include "traverse_body.inc"
+#undef RT_TWO_SIDED
 #undef RT_CAN_REFILL
     }
 #undef RT_PUSH
@@ -754,7 +763,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         // the work-queue head and ray counter are shared: reset them between the passes
         if ((e = hipMemsetAsync(a.rayCount, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
     }
-    if (cfg.stats && a.mode == RTAMD_MODE_PT && !lent) {
+    if (cfg.stats && a.mode == RTAMD_MODE_PT && !lent && !(a.flags & RTAMD_FLAG_DIELECTRICS)) {
         // diagnostic build: per-phase execution counts and active lanes, printed to stderr
         if ((e = fs.stats.ensure(16)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(fs.stats.p, 0, 16 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
@@ -769,7 +778,9 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         fprintf(stderr, "[rtamd stats] deepest traversal stack %llu of %d entries\n", h[15], kLdsStack);
         return hipSuccess;
     }
-    if (a.mode == RTAMD_MODE_PT)
+    if (a.mode == RTAMD_MODE_PT && (a.flags & RTAMD_FLAG_DIELECTRICS))
+        hipLaunchKernelGGL((kFast<kModePt, false, true>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
+    else if (a.mode == RTAMD_MODE_PT)
         hipLaunchKernelGGL((kFast<kModePt, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
     else
         hipLaunchKernelGGL((kFast<kModeRef, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);

@@ -91,7 +91,10 @@ __device__ __forceinline__ Ray poolLoadRay(const PoolRec* rec) {
 
 // STATS = true builds a diagnostic variant that also counts, per phase, how often the wave executed
 // it and with how many active lanes (written to `stats`, 16 counters; see launchPool for the names).
-template <bool STATS>
+// DIEL = true (RTAMD_FLAG_DIELECTRICS): glass objects refract; bit 16 of a record's bounce word says that
+// the path is inside glass, and such a ray tests triangles from both sides.
+constexpr int32_t kPoolInsideBit = 1 << 16;
+template <bool STATS, bool DIEL = false>
 __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene sc, Sky sky, RenderArgs a, PoolBatch b, int refillBelow,
                                                                        int nodeMin, int leafGroupMin, int stackLimit, int poolSlots,
                                                                        unsigned long long* stats) {
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
 
     // lane state
     bool trav = false, unsettled = false;
+    bool twoSided = false;        // DIEL: the ray this lane traverses is inside glass
     int32_t slot = -1;            // the path this lane traverses
     Ray world = makeRay(v3(0, 0, 0), v3(0, 0, 1));
     Ray cur = world;
@@ -196,7 +200,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                 if (inst == kPoolFresh) ended = true;
                 else {
                     const uint32_t pix = __float_as_uint(meta.y), key = __float_as_uint(meta.z);
-                    const int bounce = __float_as_int(meta.w);
+                    const int bounce = DIEL ? (__float_as_int(meta.w) & (kPoolInsideBit - 1)) : __float_as_int(meta.w);
+                    bool insideGlass = DIEL && (__float_as_int(meta.w) & kPoolInsideBit) != 0;
                     if (inst == kPoolUnsettled) { poolHandOver(a, pix); ended = true; }
                     else {
                         Ray w;
@@ -210,15 +215,15 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                             h.t = h4.x; h.u = h4.y; h.v = h4.z; h.inst = inst; h.tri = __float_as_int(h4.w);
                             const Surf sf = resolveHit(sc, w, h);
                             L = L + energy * sf.emission;
-                            V3 dir;
-                            if (bounce < a.maxBounces && scatter(sf.albedo, sf.specular, sf.normal, w.direction, key, (uint32_t)bounce, energy, dir)) {
-                                const Ray next = makeRay(sf.position + sf.normal * 0.001f, dir);
+                            V3 org, dir;
+                            if (bounce < a.maxBounces && scatterSurface<DIEL>(sf, w.direction, key, (uint32_t)bounce, energy, org, dir, insideGlass)) {
+                                const Ray next = makeRay(org, dir);
                                 write = false;
                                 if (rayDegenerate(next)) { poolHandOver(a, pix); ended = true; }
                                 else {
                                     rec->r0 = make_float4(next.origin.x, next.origin.y, next.origin.z, next.direction.x);
                                     rec->r1 = make_float4(next.direction.y, next.direction.z, next.invDir.x, next.invDir.y);
-                                    *reinterpret_cast<float4*>(&rec->invz) = make_float4(next.invDir.z, meta.y, meta.z, __int_as_float(bounce + 1));
+                                    *reinterpret_cast<float4*>(&rec->invz) = make_float4(next.invDir.z, meta.y, meta.z, __int_as_float((bounce + 1) | (insideGlass ? kPoolInsideBit : 0)));
                                     rec->energy = make_float4(energy.x, energy.y, energy.z, 0.f);
                                     rec->L = make_float4(L.x, L.y, L.z, 0.f);
                                     goOn = true;
@@ -309,6 +314,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             if (idleLane && mine < k) {
                 slot = rayQ[(rayHead + mine) & (kPoolQueue - 1)];
                 world = poolLoadRay(recs + slot);
+                if (DIEL) twoSided = (recs[slot].bounce & kPoolInsideBit) != 0;
                 cur = world;
                 best.t = RT_INF; best.u = best.v = 0; best.inst = -1; best.tri = -1;
                 secondT = RT_INF; bestNear = 0.0f;
@@ -325,7 +331,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
         }
         // a lane is served when it has a hit to publish
 #define RT_CAN_REFILL (!trav && slot >= 0)
+#define RT_TWO_SIDED (DIEL && twoSided)
 #include "traverse_body.inc"
+#undef RT_TWO_SIDED
 #undef RT_CAN_REFILL
     }
 #undef RT_PUSH
@@ -528,7 +536,8 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             }
             if ((e = ph.eventsFor(ph.nTimed)) != hipSuccess) return e;
             if ((e = hipEventRecord(ph.evBegin[ph.nTimed], stream)) != hipSuccess) return e;
-            if (cfg.stats) hipLaunchKernelGGL(kPool<true>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots, fs.stats.p);
+            if (a.flags & RTAMD_FLAG_DIELECTRICS) hipLaunchKernelGGL((kPool<false, true>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots, (unsigned long long*)nullptr);
+            else if (cfg.stats) hipLaunchKernelGGL(kPool<true>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots, fs.stats.p);
             else hipLaunchKernelGGL(kPool<false>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots, (unsigned long long*)nullptr);
             if ((e = hipEventRecord(ph.evEnd[ph.nTimed++], stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(kPoolSum, dim3((b.nWork + 255) / 256), dim3(256), 0, stream, sc, a, b);

@@ -201,7 +201,7 @@ def reference_scene(models_dir=None, width=1920, height=1080):
     return buf, frame, procedural_sky()
 
 
-def instanced_scene(width=1920, height=1080, instances=1250, tris_per_blas=40_000, seed=5, tlas_tree=0):
+def instanced_scene(width=1920, height=1080, instances=1250, tris_per_blas=40_000, seed=5, tlas_tree=0, glass_every=0):
     """Config 5 shape: many instances of a few ~40 k-triangle meshes with seeded random
     transforms (instances * tris_per_blas instanced triangles).  tlas_tree=1 builds the TLAS
     with the SAH builder (the reference's own TLAS builder gives up beyond about 1 300 objects)."""
@@ -219,6 +219,9 @@ def instanced_scene(width=1920, height=1080, instances=1250, tris_per_blas=40_00
         z = (iz - side / 2) * 2.0 + float(rs.uniform(-0.5, 0.5))
         q = H.quat_axis_angle(rs.uniform(-1, 1, size=3) + 1e-3, float(rs.uniform(0, 360)))
         col = rs.uniform(0.2, 0.9, size=3)
+        if glass_every and i % glass_every == 0:      # the "diffuse + dielectric" variant: every n-th instance is tinted glass
+            sys.AddEntity(blas[i % 3], H.trs((x, 0.8 * s, z), q, (s, s, s)), albedo=(*(0.5 + 0.5 * col), 1.5), specular=(0, 0, 0, T.MATERIAL_DIELECTRIC))
+            continue
         sys.AddEntity(blas[i % 3], H.trs((x, 0.8 * s, z), q, (s, s, s)), albedo=tuple(col), specular=(0.04, 0.04, 0.04))
     buf = sys.OnUpdate()
     sys.close()
@@ -343,3 +346,23 @@ def sliver_scene(w, h, seed, coord, inst_scale, n_tris=400, instances=12, distan
     eye = np.array([np.cos(ang) * R, rs.uniform(-0.05, 0.05) * R, np.sin(ang) * R]) if seed % 2 else np.array([R * 1e-4, R, R * 1e-4])
     frame = look_at_camera(tuple(eye), (0.0, 0.0, 0.0), float(rs.uniform(20, 60)), w, h)
     return buf, frame, procedural_sky()
+
+
+def glass_scene(width=640, height=360):
+    """Dielectric extension: two glass spheres (index 1.5 and a tinted 1.33) and a glass cube on a diffuse
+    floor next to a diffuse sphere, under an emissive quad.  Glass = specular.w 2, index of refraction
+    in albedo.w, tint in albedo.xyz (the reference never reads the fourth components)."""
+    sys = H.BuildAccelerateStructureSystem()
+    sph = sys.BakeBLAS(H.Mesh.uv_sphere(48, 24, 0.5))
+    quad = sys.BakeBLAS(H.Mesh.quad())
+    cube = sys.BakeBLAS(H.Mesh.cube())
+    sys.AddEntity(quad, H.trs((0, 0, 0), _rot_x(90), (40, 40, 1)), albedo=(0.8, 0.8, 0.8), specular=(0.04, 0.04, 0.04))
+    sys.AddEntity(sph, H.trs((-1.2, 0.75, 0), s=(1.5, 1.5, 1.5)), albedo=(1, 1, 1, 1.5), specular=(0, 0, 0, T.MATERIAL_DIELECTRIC))
+    sys.AddEntity(sph, H.trs((0.6, 0.5, -0.6), s=(1, 1, 1)), albedo=(0.6, 0.9, 0.7, 1.33), specular=(0, 0, 0, T.MATERIAL_DIELECTRIC))
+    sys.AddEntity(cube, H.trs((1.8, 0.5, 0.6), H.quat_axis_angle((0, 1, 0), 30), (1, 1, 1)), albedo=(0.9, 0.9, 1.0, 1.5),
+                  specular=(0, 0, 0, T.MATERIAL_DIELECTRIC))
+    sys.AddEntity(sph, H.trs((0.2, 0.4, 1.6), s=(0.8, 0.8, 0.8)), albedo=(0.8, 0.3, 0.2), specular=(0.1, 0.1, 0.1))
+    sys.AddEntity(quad, H.trs((0, 4, 0.5), _rot_x(-90), (3, 3, 1)), albedo=(0, 0, 0), specular=(0, 0, 0), emission=(3, 3, 3))
+    buf = sys.OnUpdate()
+    sys.close()
+    return buf, look_at_camera((0.3, 1.8, -5.5), (0.2, 0.5, 0), 40.0, width, height), procedural_sky()

@@ -22,7 +22,8 @@ assert NODE.itemsize == 116 and VERTEX.itemsize == 24 and INT3.itemsize == 12
 assert OBJECT.itemsize == 180 and FRAME.itemsize == 144
 
 MODE_REF, MODE_PT = 0, 1
-FLAG_ACCUMULATE, FLAG_NO_JITTER, FLAG_REFERENCE_ORDER, FLAG_OUTPUT_SUM, FLAG_COUNTERS, FLAG_SHARD_SAMPLES = 1, 2, 4, 8, 16, 32
+FLAG_ACCUMULATE, FLAG_NO_JITTER, FLAG_REFERENCE_ORDER, FLAG_OUTPUT_SUM, FLAG_COUNTERS, FLAG_SHARD_SAMPLES, FLAG_DIELECTRICS = 1, 2, 4, 8, 16, 32, 64
+MATERIAL_DIELECTRIC = 2.0
 
 ERRORS = {0: "OK", -1: "INVALID_ARG", -2: "BAD_INDEX", -3: "OUT_OF_MEMORY", -4: "HIP", -5: "STACK_OVERFLOW",
           -6: "NO_SCENE", -7: "NO_DEVICE"}
