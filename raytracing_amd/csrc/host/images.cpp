@@ -58,7 +58,7 @@ float halfToFloat(uint16_t h) {
 
 struct Reader {
     const uint8_t* p; size_t n, at = 0; bool ok = true;
-    bool need(size_t k) { if (at + k > n) { ok = false; return false; } return true; }
+    bool need(size_t k) { if (k > n || at > n - k) { ok = false; return false; } return true; }   // (no wrap-around for a hostile `at`)
     uint8_t u8() { if (!need(1)) return 0; return p[at++]; }
     int32_t i32() { if (!need(4)) return 0; int32_t v; std::memcpy(&v, p + at, 4); at += 4; return v; }
     uint64_t u64() { if (!need(8)) return 0; uint64_t v; std::memcpy(&v, p + at, 8); at += 8; return v; }
@@ -138,8 +138,9 @@ bool loadExr(const std::vector<uint8_t>& file, bool flip, std::vector<float>& rg
         r.at += (size_t)size;
     }
     (void)lineOrder;   // chunks carry their own y
-    W = dw[2] - dw[0] + 1; H = dw[3] - dw[1] + 1;
-    if (W <= 0 || H <= 0 || (int64_t)W * H > (1ll << 28)) { setLastError("bad OpenEXR data window"); return false; }
+    const int64_t W64 = (int64_t)dw[2] - (int64_t)dw[0] + 1, H64 = (int64_t)dw[3] - (int64_t)dw[1] + 1;
+    if (W64 <= 0 || H64 <= 0 || W64 > (1ll << 28) || H64 > (1ll << 28) || W64 * H64 > (1ll << 28)) { setLastError("bad OpenEXR data window"); return false; }
+    W = (int)W64; H = (int)H64;
     if (ch.empty()) { setLastError("OpenEXR file without channels"); return false; }
     int linesPerBlock;
     switch (compression) {
@@ -178,12 +179,14 @@ bool loadExr(const std::vector<uint8_t>& file, bool flip, std::vector<float>& rg
     std::vector<uint8_t> block, tmp;
     for (int ci = 0; ci < nChunks; ci++) {
         Reader c{file.data(), file.size()};
+        if (offsets[ci] >= (uint64_t)file.size()) { setLastError("OpenEXR chunk offset beyond the end of the file"); return false; }
         c.at = (size_t)offsets[ci];
         int32_t y0 = c.i32();
         int32_t size = c.i32();
         if (!c.ok || size < 0 || !c.need((size_t)size)) { setLastError("truncated OpenEXR chunk"); return false; }
-        int row0 = y0 - dw[1];
-        if (row0 < 0 || row0 >= H) { setLastError("OpenEXR chunk outside the data window"); return false; }
+        const int64_t row64 = (int64_t)y0 - (int64_t)dw[1];
+        const int row0 = (int)row64;
+        if (row64 < 0 || row64 >= H) { setLastError("OpenEXR chunk outside the data window"); return false; }
         int rows = H - row0 < linesPerBlock ? H - row0 : linesPerBlock;
         size_t expect = lineBytes * (size_t)rows;
         const uint8_t* src = file.data() + c.at;

@@ -126,6 +126,7 @@ struct rtamd_ctx {
     DevBuf<float4> accum;
     int accumW = 0, accumH = 0;
 
+    DevBuf<uchar4> tmp8;         // 8-bit staging of rtamd_composite_add / rtamd_present for host buffers
     DevBuf<float4> outRgba;      // staging when the caller passes host pointers
     DevBuf<int32_t> outIds;
     DevBuf<float> outT;
@@ -165,6 +166,21 @@ int failHip(rtamd_ctx* c, hipError_t e, const char* what) {
         hipError_t _e = (expr);                            \
         if (_e != hipSuccess) return failHip(c, _e, #expr); \
     } while (0)
+
+// No C++ exception crosses the C boundary: host-side allocation failures (vectors, strings, builder
+// threads) come back as status codes like everything else.
+template <typename F>
+int guarded(rtamd_ctx* c, F body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        try { return fail(c, RTAMD_ERR_OUT_OF_MEMORY, "host allocation failed"); } catch (...) { return RTAMD_ERR_OUT_OF_MEMORY; }
+    } catch (const std::exception& e) {
+        try { return fail(c, RTAMD_ERR_HIP, std::string("internal error: ") + e.what()); } catch (...) { return RTAMD_ERR_HIP; }
+    } catch (...) {
+        try { return fail(c, RTAMD_ERR_HIP, "internal error"); } catch (...) { return RTAMD_ERR_HIP; }
+    }
+}
 
 bool isDevicePointer(const void* p) {
     if (!p) return false;
@@ -231,6 +247,7 @@ const char* rtamd_last_error_string(const rtamd_ctx* ctx) {
 }
 
 int rtamd_ctx_create(int device_ordinal, rtamd_ctx** out_ctx) {
+    return guarded(nullptr, [&]() -> int {
     if (!out_ctx) return fail(nullptr, RTAMD_ERR_INVALID_ARG, "out_ctx is NULL");
     *out_ctx = nullptr;
     int count = 0;
@@ -254,6 +271,7 @@ int rtamd_ctx_create(int device_ordinal, rtamd_ctx** out_ctx) {
     c->fast.hSuper.reserve((size_t)kNaMaxTiles);     // the tile list of a launch never grows the heap after this
     *out_ctx = c;
     return RTAMD_OK;
+    });
 }
 
 int rtamd_ctx_destroy(rtamd_ctx* c) {
@@ -274,7 +292,7 @@ int rtamd_ctx_destroy(rtamd_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->tlas.release(); c->blas.release(); c->blasOffsets.release(); c->vtxOffsets.release(); c->triOffsets.release();
     c->verts.release(); c->tris.release(); c->objects.release(); c->sky.release(); c->accum.release();
-    c->outRgba.release(); c->outIds.release(); c->outT.release(); c->counters.release(); c->rayCount.release();
+    c->tmp8.release(); c->outRgba.release(); c->outIds.release(); c->outT.release(); c->counters.release(); c->rayCount.release();
     c->errorFlag.release(); c->redoMask.release(); c->redoList.release(); c->redoCount.release(); c->redoSamples.release();
     c->fast.release();
     c->pool.release();
@@ -317,6 +335,7 @@ static int uploadTlasAndObjects(rtamd_ctx* c, const rtamd_node* tlas, int nTlas,
     for (int o = 0; o < nObjects; o++)
         if (objects[o].BLASIndex < 0 || objects[o].BLASIndex >= c->nBlas)
             return fail(c, RTAMD_ERR_BAD_INDEX, "object BLASIndex out of range");
+    c->haveScene = false;      // from here on device state changes; a call rejected above leaves the last good scene in place
     HIP_TRY(c, c->tlas.upload(tlas, nTlas, c->stream));
     HIP_TRY(c, c->objects.upload(objects, nObjects, c->stream));
     c->nTlas = nTlas;
@@ -333,6 +352,7 @@ int rtamd_scene_upload(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas, cons
                        const rtamd_node* blas, int32_t nBlasNodes, const int32_t* vtxOffsets,
                        const rtamd_vertex* verts, int32_t nVerts, const int32_t* triOffsets, const rtamd_int3* tris,
                        int32_t nTris, int32_t nBlas, const rtamd_object_property* objects, int32_t nObjects) {
+    return guarded(c, [&]() -> int {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (!c->subs.empty()) {
         // the scene is replicated: every device re-packs and uploads it, all at once
@@ -390,24 +410,27 @@ int rtamd_scene_upload(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas, cons
     if (rc) return rc;
     c->haveScene = true;
     return RTAMD_OK;
+    });
 }
 
 int rtamd_scene_refresh_objects(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas,
                                 const rtamd_object_property* objects, int32_t nObjects) {
+    return guarded(c, [&]() -> int {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (!c->subs.empty()) return multi::forEach(c, [&](rtamd_ctx* sub) { return rtamd_scene_refresh_objects(sub, tlas, nTlas, objects, nObjects); });
     if (!c->haveScene) return fail(c, RTAMD_ERR_NO_SCENE, "refresh before a scene upload");
     if (!tlas || !objects || nTlas < 2) return fail(c, RTAMD_ERR_INVALID_ARG, "NULL / empty buffer");
     if (nObjects != c->nObjects) return fail(c, RTAMD_ERR_INVALID_ARG, "object count differs from the uploaded scene");
     HIP_TRY(c, hipSetDevice(c->device));
-    c->haveScene = false;
     int rc = uploadTlasAndObjects(c, tlas, nTlas, objects, nObjects);
     if (rc) return rc;
     c->haveScene = true;
     return RTAMD_OK;
+    });
 }
 
 int rtamd_sky_upload(rtamd_ctx* c, const float* rgba, int32_t w, int32_t h) {
+    return guarded(c, [&]() -> int {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (!c->subs.empty()) return multi::forEach(c, [&](rtamd_ctx* sub) { return rtamd_sky_upload(sub, rgba, w, h); });
     HIP_TRY(c, hipSetDevice(c->device));
@@ -420,6 +443,7 @@ int rtamd_sky_upload(rtamd_ctx* c, const float* rgba, int32_t w, int32_t h) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->skyW = w; c->skyH = h;
     return RTAMD_OK;
+    });
 }
 
 int rtamd_accum_reset(rtamd_ctx* c) {
@@ -489,7 +513,8 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
     }
     a.shardRank = e.shard_rank; a.shardCount = e.shard_count;
     a.flags = e.flags;
-    bool wantCounters = (e.flags & RTAMD_FLAG_COUNTERS) && e.out_counters;
+    if ((e.flags & RTAMD_FLAG_COUNTERS) && !e.out_counters) return fail(c, RTAMD_ERR_INVALID_ARG, "RTAMD_FLAG_COUNTERS needs ext.out_counters");
+    bool wantCounters = (e.flags & RTAMD_FLAG_COUNTERS) != 0;
     bool faithful = (e.flags & RTAMD_FLAG_REFERENCE_ORDER) || wantCounters;
 
     // outputs: device pointers are written in place, host pointers go through staging
@@ -886,6 +911,7 @@ int render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_param
 extern "C" {
 
 int rtamd_ctx_create_multi(const int32_t* device_ordinals, int32_t n_devices, rtamd_ctx** out_ctx) {
+    return guarded(nullptr, [&]() -> int {
     if (!out_ctx) return fail(nullptr, RTAMD_ERR_INVALID_ARG, "out_ctx is NULL");
     *out_ctx = nullptr;
     if (!device_ordinals || n_devices < 1 || n_devices > kMaxDevices) return fail(nullptr, RTAMD_ERR_INVALID_ARG, "device list is NULL, empty or longer than 64");
@@ -934,6 +960,7 @@ int rtamd_ctx_create_multi(const int32_t* device_ordinals, int32_t n_devices, rt
     (void)hipSetDevice(device_ordinals[0]);
     *out_ctx = c;
     return RTAMD_OK;
+    });
 }
 
 int rtamd_multi_info(const rtamd_ctx* c, int32_t* n_devices, int32_t* rccl_ranks, float* last_exchange_ms) {
@@ -948,14 +975,18 @@ const char* rtamd_multi_exchange_note(const rtamd_ctx* c) { return c ? c->exchan
 
 int rtamd_render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_params* ext, int32_t width,
                  int32_t height, float* out_rgba, int32_t* out_prim_id) {
+    return guarded(c, [&]() -> int {
     if (c && !c->subs.empty()) return multi::render(c, frame, ext, width, height, out_rgba, out_prim_id);
     return renderCore(c, frame, ext, width, height, out_rgba, out_prim_id, false);
+    });
 }
 
 int rtamd_render_noalloc(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_params* ext, int32_t width,
                          int32_t height, float* out_rgba_device, int32_t* out_prim_id_device) {
+    return guarded(c, [&]() -> int {
     if (c && !c->subs.empty()) return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_noalloc: not available on a context over several GPUs (the exchange buffers are sized to the frame)");
     return renderCore(c, frame, ext, width, height, out_rgba_device, out_prim_id_device, true);
+    });
 }
 
 int rtamd_last_trace_kernel_ms(const rtamd_ctx* c, float* ms) {
@@ -998,6 +1029,7 @@ __global__ void kCompositeAdd(const float4* src, uchar4* dst, size_t n) {
 }  // namespace rt
 
 extern "C" int rtamd_composite_add(rtamd_ctx* c, const float* src, uint8_t* dst, int32_t width, int32_t height) {
+    return guarded(c, [&]() -> int {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (!c->subs.empty()) return rtamd_composite_add(c->subs[0], src, dst, width, height);
     if (!src || !dst || width <= 0 || height <= 0) return fail(c, RTAMD_ERR_INVALID_ARG, "NULL buffer or bad size");
@@ -1007,7 +1039,7 @@ extern "C" int rtamd_composite_add(rtamd_ctx* c, const float* src, uint8_t* dst,
     if (sDev != dDev) return fail(c, RTAMD_ERR_INVALID_ARG, "src and dst must both be host or both be device memory");
     const float4* ds = (const float4*)src;
     uchar4* dd = (uchar4*)dst;
-    DevBuf<uchar4> tmp;
+    DevBuf<uchar4>& tmp = c->tmp8;
     if (!sDev) {
         HIP_TRY(c, c->outRgba.upload((const float4*)src, n, c->stream));
         HIP_TRY(c, tmp.upload((const uchar4*)dst, n, c->stream));
@@ -1017,8 +1049,8 @@ extern "C" int rtamd_composite_add(rtamd_ctx* c, const float* src, uint8_t* dst,
     HIP_TRY(c, hipGetLastError());
     if (!sDev) HIP_TRY(c, hipMemcpyAsync(dst, dd, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    tmp.release();
     return RTAMD_OK;
+    });
 }
 
 namespace rt {
@@ -1041,6 +1073,7 @@ __global__ void kPresent(const float4* src, uchar4* dst, size_t n, int tonemap, 
 
 extern "C" int rtamd_present(rtamd_ctx* c, const float* src, uint8_t* dst, int32_t width, int32_t height, int32_t tonemap,
                              float exposure, float gamma) {
+    return guarded(c, [&]() -> int {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (!c->subs.empty()) return rtamd_present(c->subs[0], src, dst, width, height, tonemap, exposure, gamma);
     if (!src || !dst || width <= 0 || height <= 0) return fail(c, RTAMD_ERR_INVALID_ARG, "NULL buffer or bad size");
@@ -1052,7 +1085,7 @@ extern "C" int rtamd_present(rtamd_ctx* c, const float* src, uint8_t* dst, int32
     if (sDev != dDev) return fail(c, RTAMD_ERR_INVALID_ARG, "src and dst must both be host or both be device memory");
     const float4* ds = (const float4*)src;
     uchar4* dd = (uchar4*)dst;
-    DevBuf<uchar4> tmp;
+    DevBuf<uchar4>& tmp = c->tmp8;
     if (!sDev) {
         HIP_TRY(c, c->outRgba.upload((const float4*)src, n, c->stream));
         HIP_TRY(c, tmp.alloc(n));
@@ -1063,6 +1096,6 @@ extern "C" int rtamd_present(rtamd_ctx* c, const float* src, uint8_t* dst, int32
     HIP_TRY(c, hipGetLastError());
     if (!sDev) HIP_TRY(c, hipMemcpyAsync(dst, dd, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    tmp.release();
     return RTAMD_OK;
+    });
 }

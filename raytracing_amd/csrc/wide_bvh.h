@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <new>
 #include <cstdint>
 #include <cstring>
 #include <thread>
@@ -58,6 +59,7 @@ struct Builder {
     WideTree* out;
     int maxLeaf;
     std::atomic<int>* threads;       // builder threads running, shared by the whole build
+    std::atomic<bool>* failed;       // a builder thread ran out of memory: the caller throws std::bad_alloc after all have joined
 
     void bounds(int lo, int hi, float blo[3], float bhi[3]) const {
         for (int k = 0; k < 3; k++) { blo[k] = __builtin_inff(); bhi[k] = -__builtin_inff(); }
@@ -186,19 +188,32 @@ struct Builder {
                 j.tree.nodes.emplace_back();
                 const int jlo = segs[s].lo, jhi = segs[s].hi;
                 WideTree* jt = &j.tree;
-                j.th = std::thread([this, jt, jlo, jhi, depth]() {
-                    Builder sub = *this;
-                    sub.out = jt;
-                    sub.buildNode(0, jlo, jhi, depth + 1);
+                try {
+                    j.th = std::thread([this, jt, jlo, jhi, depth]() {
+                        // (an exception must not leave a thread: it would end the process)
+                        try {
+                            Builder sub = *this;
+                            sub.out = jt;
+                            sub.buildNode(0, jlo, jhi, depth + 1);
+                        } catch (...) { failed->store(true); }
+                        threads->fetch_sub(1);
+                    });
+                } catch (...) {
+                    // no thread to be had: build this subtree here after all
                     threads->fetch_sub(1);
-                });
+                    nJobs--;
+                    j.tree.nodes.clear();
+                    try { buildNode(childNode[s], jlo, jhi, depth + 1); } catch (...) { failed->store(true); }
+                }
             } else {
                 if (n >= kSpawnMin) threads->fetch_sub(1);
-                buildNode(childNode[s], segs[s].lo, segs[s].hi, depth + 1);
+                try { buildNode(childNode[s], segs[s].lo, segs[s].hi, depth + 1); } catch (...) { failed->store(true); }
             }
         }
+        // every started thread is joined before anything can leave this frame
+        for (int k = 0; k < nJobs; k++) jobs[k].th.join();
+        if (failed->load()) return;
         for (int k = 0; k < nJobs; k++) {
-            jobs[k].th.join();
             // node 0 of the private array is the child itself, the others are appended
             const WideTree& t = jobs[k].tree;
             const int32_t base = (int32_t)out->nodes.size() - 1;
@@ -224,6 +239,8 @@ inline void buildWideTree(const BuildBox* boxes, int n, int maxLeaf, WideTree& o
     widebvh::Builder b;
     std::vector<widebvh::Item> items((size_t)n);
     std::atomic<int> threads(0);
+    std::atomic<bool> failed(false);
+    b.failed = &failed;
     b.boxes = boxes;
     b.items = items.data();
     b.out = &out;
@@ -242,6 +259,7 @@ inline void buildWideTree(const BuildBox* boxes, int n, int maxLeaf, WideTree& o
             for (int k = 0; k < 3; k++) { nd.lo[s][k] = __builtin_inff(); nd.hi[s][k] = __builtin_inff(); }
         }
     }
+    if (failed.load()) throw std::bad_alloc();
     out.order.resize(n);
     for (int i = 0; i < n; i++) out.order[i] = items[i].index;
 }

@@ -321,3 +321,49 @@ def test_sample_shards_sum_to_the_whole(gpu_pass, oracle, scene_random_small):
     mean = total[..., :3] / total[..., 3:4]
     whole = gpu_pass.Execute(frame, w, h, out_rgba=True, spp=12, **kw)["rgba"]
     np.testing.assert_allclose(mean, whole[..., :3], rtol=2e-6, atol=1e-6)      # same 12 samples, added in a different order
+
+
+def test_rejected_refresh_keeps_the_last_good_scene(oracle, scene_few):
+    """A refresh whose TLAS or object array fails validation changes nothing on the device: the next
+    frame renders the last good buffers, as the reference would keep drawing them."""
+    buf, frame, sky = scene_few
+    p = backend.RayTracingPass(0)
+    try:
+        p.SetScene(buf)
+        p.SetSkyBox(sky)
+        good = p.Execute(frame, 64, 36, out_rgba=True, out_prim_id=True, mode=T.MODE_REF)
+        bad = H.SceneBuffers(buf.tlas.copy(), buf.blas_offsets, buf.blas, buf.vertices_offsets, buf.vertices,
+                             buf.triangles_offsets, buf.triangles, buf.objects.copy())
+        bad.tlas["Data"][1][0] = 10 ** 6
+        with pytest.raises(backend.BackendError) as ei:
+            p.RefreshObjects(bad)
+        assert ei.value.code == -2
+        bad.tlas = buf.tlas
+        bad.objects["BLASIndex"][1] = 99
+        with pytest.raises(backend.BackendError) as ei:
+            p.RefreshObjects(bad)
+        assert ei.value.code == -2
+        again = p.Execute(frame, 64, 36, out_rgba=True, out_prim_id=True, mode=T.MODE_REF)
+        assert np.array_equal(good["rgba"], again["rgba"]) and np.array_equal(good["ids"], again["ids"])
+        # the counters flag without a place to put them is an argument error
+        e = p.ext(mode=T.MODE_REF)
+        e.flags = T.FLAG_COUNTERS
+        assert backend.lib().rtamd_render(p._ctx, frame.ctypes.data_as(C.c_void_p), C.byref(e), 64, 36, None, None) == -1
+    finally:
+        p.Dispose()
+
+
+def test_many_batches_are_all_timed(gpu_pass, monkeypatch):
+    """A frame rendered in more than 32 launches of the path kernel (small sample buffer): the reported
+    time of that kernel covers every launch, so it stays below the whole call's device time and close to it."""
+    buf, frame, sky = scenes.random_spheres(320, 180)
+    gpu_pass.SetScene(buf)
+    gpu_pass.SetSkyBox(sky)
+    kw = dict(mode=T.MODE_PT, spp=40, max_bounces=6, seed=3)
+    whole = gpu_pass.Execute(frame, 320, 180, out_rgba=True, **kw)
+    monkeypatch.setenv("RTAMD_POOL_MAX_PATHS", "61440")       # 60 tiles x 1024 work items: one sample per batch, 40 batches
+    many = gpu_pass.Execute(frame, 320, 180, out_rgba=True, **kw)
+    monkeypatch.delenv("RTAMD_POOL_MAX_PATHS")
+    assert np.array_equal(whole["rgba"], many["rgba"]) and whole["rays"] == many["rays"]
+    assert many["trace_ms"] <= many["kernel_ms"]
+    assert many["trace_ms"] > 0.6 * (many["kernel_ms"] - many["handover_ms"])

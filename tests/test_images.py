@@ -217,3 +217,35 @@ def test_writers_round_trip(tmp_path):
     assert np.array_equal(px, want)
     with pytest.raises(H.HostError):
         H.save_image(tmp_path / "out.png", img)
+
+
+def test_exr_hostile_offsets_and_windows_are_errors(tmp_path):
+    """A chunk offset near 2^64 (which would wrap the bounds check), one just past the end of the file, and
+    a data window whose extent overflows 32 bits must all be refused, not read out of bounds."""
+    img = _picture(4, 4, 2)
+    good = tmp_path / "good.exr"
+    write_exr(good, img[..., [3, 2, 1, 0]], 2, 0)
+    data = bytearray(good.read_bytes())
+    H.load_image(good)
+    # the offset table is the 4 x 8 bytes in front of the first chunk: find it through the first offset value
+    first = None
+    for at in range(0, len(data) - 8):
+        if struct.unpack_from("<Q", data, at)[0] == at + 32:
+            first = at
+            break
+    assert first is not None
+    for bad in (2 ** 64 - 4, 2 ** 64 - 1, len(data), len(data) - 2, 2 ** 40):
+        d = bytearray(data)
+        struct.pack_into("<Q", d, first + 8, bad)
+        p = tmp_path / "bad.exr"
+        p.write_bytes(bytes(d))
+        with pytest.raises(H.HostError):
+            H.load_image(p)
+    # data window (x0, y0, x1, y1) = (-2^31, 0, 2^31 - 1, 3): width overflows int
+    at = bytes(data).index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+    d = bytearray(data)
+    struct.pack_into("<iiii", d, at, -2 ** 31, 0, 2 ** 31 - 1, 3)
+    p = tmp_path / "wide.exr"
+    p.write_bytes(bytes(d))
+    with pytest.raises(H.HostError, match="data window"):
+        H.load_image(p)
