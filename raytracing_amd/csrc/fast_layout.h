@@ -31,7 +31,7 @@ struct FastScene {
     const FTri* tris;
     const FNrm* nrms;            // by triangle rank
     const int32_t* triOrig;      // by triangle rank: the caller's triangle index
-    const int32_t* superTiles;   // ids of the 32x32 pixel tiles this launch owns
+    const int32_t* superTiles;   // the 32x32 pixel tiles this launch owns: tile column | tile row << 16
     int32_t nSuperTiles;
     int32_t tlasRoot;            // index of the TLAS root in nodes
     // nodes kept in LDS by every workgroup: [0, hotTlas) and [blasBase, blasBase + hotBlas)

@@ -592,10 +592,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
                     unsigned long long w = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
                     if (w >= totalWork) noMoreWork = true;
                     else {
-                        int st = sc.superTiles[(int)(w >> 10)];
+                        int st = sc.superTiles[(int)(w >> 10)];       // tile column | tile row << 16
                         int within = (int)(w & 1023ull);
-                        int tilesX = (a.width + 31) / 32;
-                        int sx = st % tilesX, sy = st / tilesX;
+                        int sx = st & 0xffff, sy = st >> 16;
                         int t8 = within >> 6, p8 = within & 63;
                         int x = sx * 32 + (t8 & 3) * 8 + (p8 & 7);
                         int y = sy * 32 + (t8 >> 2) * 8 + (p8 >> 3);
@@ -708,7 +707,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         for (int sx = sx0; sx <= sx1; sx++) {
             int id = sy * tilesX + sx;
             if (a.shardCount > 1 && id % a.shardCount != a.shardRank) continue;
-            fs.hSuper.push_back(id);
+            fs.hSuper.push_back(sx | (sy << 16));
         }
     if (fs.hSuper.empty()) return hipSuccess;
     hipError_t e;

@@ -59,10 +59,9 @@ struct PoolBatch {
 
 // work item -> pixel; false when the item lies outside the image or the requested rectangle
 __device__ __forceinline__ bool poolPixel(const FastScene& sc, const RenderArgs& a, const PoolBatch& b, uint32_t w, int& x, int& y) {
-    const int st = sc.superTiles[b.superBase + (int)(w >> 10)];
+    const int st = sc.superTiles[b.superBase + (int)(w >> 10)];     // tile column | tile row << 16
     const int within = (int)(w & 1023u);
-    const int tilesX = (a.width + 31) / 32;
-    const int sx = st % tilesX, sy = st / tilesX;
+    const int sx = st & 0xffff, sy = st >> 16;
     const int t8 = within >> 6, p8 = within & 63;
     x = sx * 32 + (t8 & 3) * 8 + (p8 & 7);
     y = sy * 32 + (t8 >> 2) * 8 + (p8 >> 3);
@@ -90,7 +89,7 @@ __device__ __forceinline__ Ray poolLoadRay(const PoolRec* rec) {
 }
 
 // STATS = true builds a diagnostic variant that also counts, per phase, how often the wave executed
-// it and with how many active lanes (written to `stats`, 16 counters; see launchPool for the names).
+// it and with how many active lanes (written to `stats`, 24 counters; see launchPool for the names).
 // DIEL = true (RTAMD_FLAG_DIELECTRICS): glass objects refract; bit 16 of a record's bounce word says that
 // the path is inside glass, and such a ray tests triangles from both sides.
 constexpr int32_t kPoolInsideBit = 1 << 16;
@@ -98,7 +97,7 @@ template <bool STATS, bool DIEL = false>
 __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene sc, Sky sky, RenderArgs a, PoolBatch b, int refillBelow,
                                                                        int nodeMin, int leafGroupMin, int stackLimit, int poolSlots,
                                                                        unsigned long long* stats) {
-    unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define RT_STAT(slot, cond)                                                         \
     do {                                                                            \
         if (STATS) {                                                                \
@@ -108,12 +107,15 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
     } while (0)
     __shared__ int32_t ldsStack[kLdsStack][kBlockThreads];
     __shared__ float4 ldsNodes[kPoolHotNodes * kHotStride];
-    __shared__ uint16_t ldsQueues[kBlockThreads / 64][2][kPoolQueue];
+    __shared__ uint8_t ldsQueues[kBlockThreads / 64][3][kPoolQueue];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    uint16_t* const rayQ = ldsQueues[wave][0];     // paths with a ray ready to traverse
-    uint16_t* const hitQ = ldsQueues[wave][1];     // paths whose ray has been traversed (or that need a first ray)
+    // three queues of record slots, private to the wave:
+    uint8_t* const rayQ = ldsQueues[wave][0];     // paths with a ray ready to traverse
+    uint8_t* const hitQ = ldsQueues[wave][1];     // paths whose ray hit a surface: to be shaded and scattered
+    uint8_t* const endQ = ldsQueues[wave][2];     // paths whose ray left the scene, that ended at a surface, that cannot be settled here,
+                                                  // and records without a path: each gets (its sky light and) the next path of the batch
     PoolRec* const recs = b.recs + ((size_t)blockIdx.x * (kBlockThreads / 64) + wave) * kPoolSlots;
     const unsigned long long totalPaths = (unsigned long long)b.nWork * (unsigned long long)b.nSamples;
     const unsigned long long laneBelow = (1ull << lane) - 1ull;
@@ -127,9 +129,11 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
     __syncthreads();
 
     // the same in every lane of the wave
-    int rayHead = 0, rayTail = 0, hitHead = 0, hitTail = 0;
+    int rayHead = 0, rayTail = 0, hitHead = 0, hitTail = 0, endHead = 0, endTail = 0;
     int nAlloc = 0;               // record slots handed out so far
     unsigned long long pathNext = 0, pathEnd = 0;   // the wave's current chunk of path indices
+    uint32_t nextItem = 0;        // pathNext as (sample, work item): pathNext = nextSmp * nWork + nextItem
+    int nextSmp = 0;
     bool noMoreWork = false;
 
     // lane state
@@ -153,97 +157,124 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
 #define RT_REDO() do { unsettled = true; trav = false; } while (0)
 
     for (;;) {
-        // ---------------------------------------- finished lanes publish their hits
+        // ---------------------------------------- finished lanes publish their results
         {
             const bool fin = !trav && slot >= 0;
-            const unsigned long long m = __ballot(fin);
+            const bool amb = best.t < RT_INF && secondT < bestNear;   // order-dependent in the reference: see kernel_fast.h
+            const bool toHit = fin && best.inst >= 0 && !unsettled && !amb;
+            const unsigned long long mh = __ballot(toHit), me = __ballot(fin && !toHit);
             RT_STAT(5, fin);
             if (fin) {
                 PoolRec* rec = recs + slot;
-                const bool amb = best.t < RT_INF && secondT < bestNear;   // order-dependent in the reference: see kernel_fast.h
-                rec->hit = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
-                rec->inst = (unsettled || amb) ? kPoolUnsettled : best.inst;
-                hitQ[(hitTail + __popcll(m & laneBelow)) & (kPoolQueue - 1)] = (uint16_t)slot;
+                if (toHit) {
+                    rec->hit = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
+                    rec->inst = best.inst;
+                    hitQ[(hitTail + __popcll(mh & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)slot;
+                } else {
+                    rec->inst = (unsettled || amb) ? kPoolUnsettled : kPoolMiss;
+                    endQ[(endTail + __popcll(me & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)slot;
+                }
                 slot = -1;
             }
-            hitTail += __popcll(m);
+            hitTail += __popcll(mh);
+            endTail += __popcll(me);
             __threadfence_block();      // records and queue entries are read by other lanes of the wave below
         }
-        // ---------------------------------------- shade 64 queued paths at a time, all lanes busy
+        // ---------------------------------------- shading passes, 64 queued paths at a time, one kind of work per pass
         for (;;) {
             const int idle = __popcll(__ballot(!trav));
-            const int hitCnt = hitTail - hitHead, rayCnt = rayTail - rayHead;
-            int nShade = 0;
-            if (hitCnt >= 64 || (hitCnt > 0 && rayCnt < idle)) nShade = hitCnt < 64 ? hitCnt : 64;
-            int nNew = 0;     // unused lanes of the pass start brand-new paths while record slots are left
-            if (!noMoreWork && nAlloc < poolSlots && (nShade > 0 || rayCnt < idle)) {
-                nNew = 64 - nShade;
-                if (nNew > poolSlots - nAlloc) nNew = poolSlots - nAlloc;
+            const int hitCnt = hitTail - hitHead, endCnt = endTail - endHead, rayCnt = rayTail - rayHead;
+            const bool canStart = !noMoreWork && nAlloc < poolSlots;       // record slots never used so far
+            int kind = 0;             // 1: surface hits; 2: path ends and starts
+            if (hitCnt >= 64) kind = 1;
+            else if (endCnt >= 64) kind = 2;
+            else if (rayCnt < idle) {
+                // lanes would go idle: whichever queue holds more, or brand-new paths
+                if (hitCnt > 0 && hitCnt >= endCnt) kind = 1;
+                else if (endCnt > 0 || canStart) kind = 2;
             }
-            if (nShade + nNew == 0) break;
+            if (kind == 0) break;
             __builtin_amdgcn_wave_barrier();
-            int32_t s = -1;
-            if (lane < nShade) s = hitQ[(hitHead + lane) & (kPoolQueue - 1)];
-            else if (lane < nShade + nNew) s = nAlloc + (lane - nShade);
-            hitHead += nShade;
-            nAlloc += nNew;
-
             bool goOn = false, ended = false;
-            RT_STAT(0, s >= 0);
-            if (s >= 0) {
-                PoolRec* rec = recs + s;
-                // (the whole record at once: one round trip)
-                const int32_t instRec = rec->inst;
-                const float4 meta = *reinterpret_cast<const float4*>(&rec->invz);
-                const float4 r0 = rec->r0, r1 = rec->r1, e4 = rec->energy, l4 = rec->L, h4 = rec->hit;
-                const int32_t inst = lane < nShade ? instRec : kPoolFresh;
-                if (inst == kPoolFresh) ended = true;
-                else {
-                    const uint32_t pix = __float_as_uint(meta.y), key = __float_as_uint(meta.z);
+            int32_t s = -1;
+            if (kind == 1) {
+                // ---- surface hits: emission, scattering, the next ray
+                const int n = hitCnt < 64 ? hitCnt : 64;
+                if (lane < n) s = hitQ[(hitHead + lane) & (kPoolQueue - 1)];
+                hitHead += n;
+                RT_STAT(0, s >= 0);
+                if (s >= 0) {
+                    PoolRec* rec = recs + s;
+                    const int32_t inst = rec->inst;
+                    const float4 meta = *reinterpret_cast<const float4*>(&rec->invz);
+                    const float4 r0 = rec->r0, r1 = rec->r1, e4 = rec->energy, l4 = rec->L, h4 = rec->hit;
+                    const uint32_t pix = __float_as_uint(meta.y);
+                    const uint32_t key = __float_as_uint(meta.z);
                     const int bounce = DIEL ? (__float_as_int(meta.w) & (kPoolInsideBit - 1)) : __float_as_int(meta.w);
                     bool insideGlass = DIEL && (__float_as_int(meta.w) & kPoolInsideBit) != 0;
-                    if (inst == kPoolUnsettled) { poolHandOver(a, pix); ended = true; }
-                    else {
-                        Ray w;
-                        w.origin = v3(r0.x, r0.y, r0.z);
-                        w.direction = v3(r0.w, r1.x, r1.y);
-                        w.invDir = v3(r1.z, r1.w, meta.x);
-                        V3 energy = v3(e4.x, e4.y, e4.z), L = v3(l4.x, l4.y, l4.z);
-                        bool write = true;
-                        if (inst >= 0) {
-                            FastHit h;
-                            h.t = h4.x; h.u = h4.y; h.v = h4.z; h.inst = inst; h.tri = __float_as_int(h4.w);
-                            const Surf sf = resolveHit(sc, w, h);
-                            L = L + energy * sf.emission;
-                            V3 org, dir;
-                            if (bounce < a.maxBounces && scatterSurface<DIEL>(sf, w.direction, key, (uint32_t)bounce, energy, org, dir, insideGlass)) {
-                                const Ray next = makeRay(org, dir);
-                                write = false;
-                                if (rayDegenerate(next)) { poolHandOver(a, pix); ended = true; }
-                                else {
-                                    rec->r0 = make_float4(next.origin.x, next.origin.y, next.origin.z, next.direction.x);
-                                    rec->r1 = make_float4(next.direction.y, next.direction.z, next.invDir.x, next.invDir.y);
-                                    *reinterpret_cast<float4*>(&rec->invz) = make_float4(next.invDir.z, meta.y, meta.z, __int_as_float((bounce + 1) | (insideGlass ? kPoolInsideBit : 0)));
-                                    rec->energy = make_float4(energy.x, energy.y, energy.z, 0.f);
-                                    rec->L = make_float4(L.x, L.y, L.z, 0.f);
-                                    goOn = true;
-                                }
-                            }
-                        } else {
-                            L = L + energy * shadeMiss(sky, w.direction);
+                    Ray w;
+                    w.origin = v3(r0.x, r0.y, r0.z);
+                    w.direction = v3(r0.w, r1.x, r1.y);
+                    w.invDir = v3(r1.z, r1.w, meta.x);
+                    V3 energy = v3(e4.x, e4.y, e4.z), L = v3(l4.x, l4.y, l4.z);
+                    FastHit h;
+                    h.t = h4.x; h.u = h4.y; h.v = h4.z; h.inst = inst; h.tri = __float_as_int(h4.w);
+                    const Surf sf = resolveHit(sc, w, h);
+                    L = L + energy * sf.emission;
+                    V3 org, dir;
+                    bool write = true;
+                    if (bounce < a.maxBounces && scatterSurface<DIEL>(sf, w.direction, key, (uint32_t)bounce, energy, org, dir, insideGlass)) {
+                        const Ray next = makeRay(org, dir);
+                        write = false;
+                        if (rayDegenerate(next)) { poolHandOver(a, pix); ended = true; }
+                        else {
+                            rec->r0 = make_float4(next.origin.x, next.origin.y, next.origin.z, next.direction.x);
+                            rec->r1 = make_float4(next.direction.y, next.direction.z, next.invDir.x, next.invDir.y);
+                            *reinterpret_cast<float4*>(&rec->invz) = make_float4(next.invDir.z, meta.y, meta.z, __int_as_float((bounce + 1) | (insideGlass ? kPoolInsideBit : 0)));
+                            rec->energy = make_float4(energy.x, energy.y, energy.z, 0.f);
+                            if (__float_as_uint(L.x) != __float_as_uint(l4.x) || __float_as_uint(L.y) != __float_as_uint(l4.y) || __float_as_uint(L.z) != __float_as_uint(l4.z))
+                                rec->L = make_float4(L.x, L.y, L.z, 0.f);      // (most surfaces emit nothing: the sum keeps its bits)
+                            goOn = true;
                         }
-                        if (write) {
+                    }
+                    if (write) {
+                        b.sampleL[rec->path] = make_float4(L.x, L.y, L.z, __int_as_float(bounce + 1));
+                        ended = true;
+                    }
+                    if (ended) rec->inst = kPoolFresh;      // the record waits in the other queue for its next path
+                }
+            } else {
+                // ---- path ends (sky light, hand-over) and starts: queued records first, then record slots never used so far
+                const int n = endCnt < 64 ? endCnt : 64;
+                int nNew = 0;
+                if (canStart) { nNew = 64 - n; if (nNew > poolSlots - nAlloc) nNew = poolSlots - nAlloc; }
+                if (lane < n) s = endQ[(endHead + lane) & (kPoolQueue - 1)];
+                else if (lane < n + nNew) s = nAlloc + (lane - n);
+                endHead += n;
+                nAlloc += nNew;
+                RT_STAT(8, s >= 0);
+                if (s >= 0) {
+                    ended = true;
+                    if (lane < n) {
+                        PoolRec* rec = recs + s;
+                        const int32_t inst = rec->inst;
+                        if (inst == kPoolMiss) {
+                            const float4 meta = *reinterpret_cast<const float4*>(&rec->invz);
+                            const float4 r0 = rec->r0, r1 = rec->r1, e4 = rec->energy, l4 = rec->L;
+                            const int bounce = DIEL ? (__float_as_int(meta.w) & (kPoolInsideBit - 1)) : __float_as_int(meta.w);
+                            V3 L = v3(l4.x, l4.y, l4.z) + v3(e4.x, e4.y, e4.z) * shadeMiss(sky, v3(r0.w, r1.x, r1.y));
                             b.sampleL[rec->path] = make_float4(L.x, L.y, L.z, __int_as_float(bounce + 1));
-                            ended = true;
+                        } else if (inst == kPoolUnsettled) {
+                            poolHandOver(a, rec->pix);
                         }
                     }
                 }
             }
-            // finished (and brand-new) paths: the record takes the next (pixel, sample) of the batch
-            bool fresh = false;      // the record holds a fresh placeholder that has to come round again
+            // ended (and never used) records take the next (pixel, sample) of the batch
+            bool fresh = false;      // the record holds a placeholder that has to come round again
             {
                 const unsigned long long me = __ballot(ended);
-                if (me != 0ull && !noMoreWork) {
+                if (kind == 2 && me != 0ull && !noMoreWork) {
                     // path indices come in chunks of b.chunk per wave (one atomic per chunk); a lane
                     // that finds the chunk used up keeps a placeholder and asks again in the next pass
                     if (pathNext == pathEnd) {
@@ -251,20 +282,31 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                         if (lane == 0) got = atomicAdd(b.next, (unsigned long long)b.chunk);
                         got = __shfl(got, 0, 64);
                         if (got >= totalPaths) noMoreWork = true;
-                        else { pathNext = got; pathEnd = totalPaths - got < (unsigned long long)b.chunk ? totalPaths : got + b.chunk; }
+                        else {
+                            pathNext = got; pathEnd = totalPaths - got < (unsigned long long)b.chunk ? totalPaths : got + b.chunk;
+                            nextSmp = (int)(got / b.nWork);                 // (one division per chunk, not per path)
+                            nextItem = (uint32_t)(got - (unsigned long long)nextSmp * b.nWork);
+                        }
                     }
                     const unsigned long long base = pathNext;
                     const unsigned long long avail = pathEnd - pathNext;
                     const unsigned long long wantN = (unsigned long long)__popcll(me);
-                    pathNext += wantN < avail ? wantN : avail;
+                    const uint32_t take = (uint32_t)(wantN < avail ? wantN : avail);
+                    const uint32_t baseItem = nextItem;
+                    const int baseSmp = nextSmp;
+                    pathNext += take;
+                    nextItem += take;
+                    if (nextItem >= b.nWork) { nextItem -= b.nWork; nextSmp++; }      // (a pass takes at most 64 <= nWork paths)
                     if (ended) {
-                        const unsigned long long p = base + (unsigned long long)__popcll(me & laneBelow);
+                        const uint32_t mine = (uint32_t)__popcll(me & laneBelow);
+                        const unsigned long long p = base + mine;
                         if (noMoreWork) { }
                         else if (p >= pathEnd) { recs[s].inst = kPoolFresh; fresh = true; }
                         else {
                             PoolRec* rec = recs + s;
-                            const uint32_t wItem = (uint32_t)(p % b.nWork);
-                            const int smp = (int)(p / b.nWork);
+                            uint32_t wItem = baseItem + mine;
+                            int smp = baseSmp;
+                            if (wItem >= b.nWork) { wItem -= b.nWork; smp++; }
                             bool live = false;
                             int x, y;
                             if (poolPixel(sc, a, b, wItem, x, y)) {
@@ -290,16 +332,16 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                             else { rec->inst = kPoolFresh; fresh = true; }     // no such path: take another one next time
                         }
                     }
-                }
+                } else if (kind == 1 && ended) fresh = true;          // ended at a surface: queued for a new path
             }
-            // queue the paths that have a ray to traverse; placeholders go back to the shading queue
+            // queue the paths that have a ray to traverse; placeholders go (back) to the end queue
             {
                 const unsigned long long mg = __ballot(goOn);
-                if (goOn) rayQ[(rayTail + __popcll(mg & laneBelow)) & (kPoolQueue - 1)] = (uint16_t)s;
+                if (goOn) rayQ[(rayTail + __popcll(mg & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)s;
                 rayTail += __popcll(mg);
                 const unsigned long long mf = __ballot(fresh);
-                if (fresh) hitQ[(hitTail + __popcll(mf & laneBelow)) & (kPoolQueue - 1)] = (uint16_t)s;
-                hitTail += __popcll(mf);
+                if (fresh) endQ[(endTail + __popcll(mf & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)s;
+                endTail += __popcll(mf);
             }
             __threadfence_block();
         }
@@ -325,11 +367,11 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             rayHead += k;
         }
         if (__ballot(trav) == 0ull) {
-            // nothing to traverse: more shading / new paths, or (both queues empty, no work left) the end
-            if (hitTail - hitHead == 0 && rayTail - rayHead == 0) break;
+            // nothing to traverse: more shading / new paths, or (all queues empty, no work left) the end
+            if (hitTail - hitHead == 0 && endTail - endHead == 0 && rayTail - rayHead == 0) break;
             continue;
         }
-        // a lane is served when it has a hit to publish
+        // a lane is served when it has a result to publish
 #define RT_CAN_REFILL (!trav && slot >= 0)
 #define RT_TWO_SIDED (DIEL && twoSided)
 #include "traverse_body.inc"
@@ -346,8 +388,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
     if (STATS) {
         for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(deepest, off, 64); deepest = o > deepest ? o : deepest; }
         if (lane == 0) {
-            for (int i = 0; i < 15; i++) if (st_[i]) atomicAdd(stats + i, st_[i]);
-            atomicMax(stats + 15, (unsigned long long)deepest);
+            for (int i = 0; i < 23; i++) if (st_[i]) atomicAdd(stats + i, st_[i]);
+            atomicMax(stats + 23, (unsigned long long)deepest);
         }
     }
 }
@@ -436,7 +478,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         for (int sx = sx0; sx <= sx1; sx++) {
             int id = sy * tilesX + sx;
             if (a.shardCount > 1 && id % a.shardCount != a.shardRank) continue;
-            fs.hSuper.push_back(id);
+            fs.hSuper.push_back(sx | (sy << 16));
         }
     if (fs.hSuper.empty()) return hipSuccess;
     hipError_t e = fs.superTiles.put(fs.hSuper, stream);
@@ -454,8 +496,8 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         // measured optima of the three benchmark scenes: shading is cheap here (full waves), so
         // lanes are refilled earlier than in kFast; small scenes (same criterion as kFast's) walk on with few lanes
         const bool allHot = fs.nBlasNodes + (size_t)fs.nTlasNodes <= (size_t)kHotNodes;
-        if (cfg.refillBelow == 0) cfg.refillBelow = allHot ? 48 : 56;
-        if (cfg.nodeMin == 0) cfg.nodeMin = allHot ? 8 : 24;
+        if (cfg.refillBelow == 0) cfg.refillBelow = 48;
+        if (cfg.nodeMin == 0) cfg.nodeMin = allHot ? 8 : 16;
     }
 
     FastScene sc;
@@ -510,8 +552,8 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     }
 
     if (cfg.stats) {
-        if ((e = fs.stats.ensure(16)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(fs.stats.p, 0, 16 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+        if ((e = fs.stats.ensure(24)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(fs.stats.p, 0, 24 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
     }
     for (size_t t0 = 0; t0 < fs.hSuper.size(); t0 += tilesPerChunk) {
         const size_t nt = fs.hSuper.size() - t0 < tilesPerChunk ? fs.hSuper.size() - t0 : tilesPerChunk;
@@ -533,6 +575,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
                 const unsigned long long perWave = total / ((unsigned long long)grid * (kBlockThreads / 64) * 8ull);
                 b.chunk = perWave >= (unsigned long long)kPoolChunk ? kPoolChunk : (perWave < 64ull ? 64 : (int)(perWave / 64ull) * 64);
                 if (const char* cv = getenv("RTAMD_POOL_CHUNK")) { int v = atoi(cv); if (v >= 1 && v <= 65536) b.chunk = v; }
+                if ((uint32_t)b.chunk > b.nWork) b.chunk = (int)b.nWork;
             }
             if ((e = ph.eventsFor(ph.nTimed)) != hipSuccess) return e;
             if ((e = hipEventRecord(ph.evBegin[ph.nTimed], stream)) != hipSuccess) return e;
@@ -546,13 +589,13 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     }
     if (cfg.stats) {
         // diagnostic build: per-phase execution counts and active lanes of the whole render, to stderr
-        unsigned long long h[16];
+        unsigned long long h[24];
         if ((e = hipMemcpyAsync(h, fs.stats.p, sizeof(h), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-        const char* names[8] = {"shadePass", "nodeStep", "instEnter", "triLeaf(slot boxes)", "triTest", "publishHit", "leafPhase(trav lanes)", "nodeLoop(trav lanes)"};
-        for (int i = 0; i < 8; i++)
+        const char* names[9] = {"hitPass", "nodeStep", "instEnter", "triLeaf(slot boxes)", "triTest", "publish", "leafPhase(trav lanes)", "nodeLoop(trav lanes)", "endStartPass"};
+        for (int i = 0; i < 9; i++)
             if (h[2 * i]) fprintf(stderr, "[rtamd stats] kPool %-22s executions %12llu  mean active lanes %6.2f\n", names[i], h[2 * i], (double)h[2 * i + 1] / (double)h[2 * i]);
-        fprintf(stderr, "[rtamd stats] kPool deepest traversal stack %llu of %d entries in LDS\n", h[15], kLdsStack);
+        fprintf(stderr, "[rtamd stats] kPool deepest traversal stack %llu of %d entries in LDS\n", h[23], kLdsStack);
     }
     return hipSuccess;
 }

@@ -462,7 +462,7 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
                       int32_t height, float* out_rgba, int32_t* out_prim_id, const bool noAlloc) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (!frame) return fail(c, RTAMD_ERR_INVALID_ARG, "frame is NULL");
-    if (width <= 0 || height <= 0 || (int64_t)width * height > (1ll << 30)) return fail(c, RTAMD_ERR_INVALID_ARG, "bad image size");
+    if (width <= 0 || height <= 0 || width > (1 << 20) || height > (1 << 20) || (int64_t)width * height > (1ll << 30)) return fail(c, RTAMD_ERR_INVALID_ARG, "bad image size");
     if (!c->haveScene) return fail(c, RTAMD_ERR_NO_SCENE, "render before a scene upload");
     rtamd_ext_params e;
     std::memset(&e, 0, sizeof(e));
@@ -734,7 +734,7 @@ static int unpackOn(rtamd_ctx* c, size_t d, T* frame, size_t offset, int w, int 
 int render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_params* ext, int32_t width, int32_t height,
            float* out_rgba, int32_t* out_prim_id) {
     if (!frame) return fail(c, RTAMD_ERR_INVALID_ARG, "frame is NULL");
-    if (width <= 0 || height <= 0 || (int64_t)width * height > (1ll << 30)) return fail(c, RTAMD_ERR_INVALID_ARG, "bad image size");
+    if (width <= 0 || height <= 0 || width > (1 << 20) || height > (1 << 20) || (int64_t)width * height > (1ll << 30)) return fail(c, RTAMD_ERR_INVALID_ARG, "bad image size");
     if (!c->haveScene) return fail(c, RTAMD_ERR_NO_SCENE, "render before a scene upload");
     rtamd_ext_params e;
     std::memset(&e, 0, sizeof(e));
