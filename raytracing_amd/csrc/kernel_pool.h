@@ -38,10 +38,10 @@ struct alignas(128) PoolRec {
 static_assert(sizeof(PoolRec) == 128, "one record per 128-byte line");
 
 constexpr int32_t kPoolMiss = -1, kPoolUnsettled = -3, kPoolFresh = -4;
-constexpr int kPoolSlots = 128;      // paths per wave
-constexpr int kPoolQueue = 128;      // entries per queue (power of two >= kPoolSlots)
-constexpr int kPoolChunk = 512;      // path indices a wave takes from the batch at a time (fewer when the batch is small)
-constexpr int kPoolHotNodes = 376;   // LDS: 96 KiB stacks + 8 KiB queues + 53 KiB nodes
+constexpr int kPoolSlots = 128;      // paths per wave (record slots); 144 .. 192 gain 1-2 % on a scene that fits the caches and lose 2-4 % on one that does not
+constexpr int kPoolQueue = 128;      // entries per queue (power of two >= kPoolSlots; a slot index fits a byte)
+constexpr int kPoolChunk = 256;      // path indices a wave takes from the batch at a time (fewer when the batch is small)
+constexpr int kPoolHotNodes = 376;   // LDS: 96 KiB stacks + 6 KiB queues + 53 KiB nodes
 
 struct PoolBatch {
     PoolRec* recs;                // [waves of the grid][kPoolSlots]
@@ -78,16 +78,6 @@ __device__ __forceinline__ void poolHandOver(const RenderArgs& a, uint32_t p) {
     }
 }
 
-__device__ __forceinline__ Ray poolLoadRay(const PoolRec* rec) {
-    const float4 r0 = rec->r0, r1 = rec->r1;
-    const float iz = rec->invz;
-    Ray r;
-    r.origin = v3(r0.x, r0.y, r0.z);
-    r.direction = v3(r0.w, r1.x, r1.y);
-    r.invDir = v3(r1.z, r1.w, iz);
-    return r;
-}
-
 // STATS = true builds a diagnostic variant that also counts, per phase, how often the wave executed
 // it and with how many active lanes (written to `stats`, 24 counters; see launchPool for the names).
 // DIEL = true (RTAMD_FLAG_DIELECTRICS): glass objects refract; bit 16 of a record's bounce word says that
@@ -116,7 +106,14 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
     uint8_t* const hitQ = ldsQueues[wave][1];     // paths whose ray hit a surface: to be shaded and scattered
     uint8_t* const endQ = ldsQueues[wave][2];     // paths whose ray left the scene, that ended at a surface, that cannot be settled here,
                                                   // and records without a path: each gets (its sky light and) the next path of the batch
-    PoolRec* const recs = b.recs + ((size_t)blockIdx.x * (kBlockThreads / 64) + wave) * kPoolSlots;
+    // The wave's records: one 128-byte line per slot, 8 pieces of 16 bytes (r0, r1, meta, hit, aux, energy, L, unused; see
+    // PoolRec).  (Piece-major storage, [piece][slot], was measured 9-22 % slower: every line then holds parts of 8 paths.)
+    float4* const recBase = reinterpret_cast<float4*>(b.recs + ((size_t)blockIdx.x * (kBlockThreads / 64) + wave) * kPoolSlots);
+#define RT_REC(piece, sl) (recBase + (sl) * 8 + (piece))
+#define RT_REC_INST(sl) (*reinterpret_cast<int32_t*>(RT_REC(4, sl)))
+#define RT_REC_PATH(sl) (reinterpret_cast<uint32_t*>(RT_REC(4, sl))[1])
+#define RT_REC_PIX(sl) (reinterpret_cast<uint32_t*>(RT_REC(2, sl))[1])
+#define RT_REC_BOUNCE(sl) (reinterpret_cast<int32_t*>(RT_REC(2, sl))[3])
     const unsigned long long totalPaths = (unsigned long long)b.nWork * (unsigned long long)b.nSamples;
     const unsigned long long laneBelow = (1ull << lane) - 1ull;
 
@@ -165,13 +162,13 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             const unsigned long long mh = __ballot(toHit), me = __ballot(fin && !toHit);
             RT_STAT(5, fin);
             if (fin) {
-                PoolRec* rec = recs + slot;
+                const int rs = slot;
                 if (toHit) {
-                    rec->hit = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
-                    rec->inst = best.inst;
+                    *RT_REC(3, rs) = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
+                    RT_REC_INST(rs) = best.inst;
                     hitQ[(hitTail + __popcll(mh & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)slot;
                 } else {
-                    rec->inst = (unsettled || amb) ? kPoolUnsettled : kPoolMiss;
+                    RT_REC_INST(rs) = (unsettled || amb) ? kPoolUnsettled : kPoolMiss;
                     endQ[(endTail + __popcll(me & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)slot;
                 }
                 slot = -1;
@@ -204,10 +201,10 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                 hitHead += n;
                 RT_STAT(0, s >= 0);
                 if (s >= 0) {
-                    PoolRec* rec = recs + s;
-                    const int32_t inst = rec->inst;
-                    const float4 meta = *reinterpret_cast<const float4*>(&rec->invz);
-                    const float4 r0 = rec->r0, r1 = rec->r1, e4 = rec->energy, l4 = rec->L, h4 = rec->hit;
+                    const int rs = s;
+                    const int32_t inst = RT_REC_INST(rs);
+                    const float4 meta = *RT_REC(2, rs);
+                    const float4 r0 = *RT_REC(0, rs), r1 = *RT_REC(1, rs), e4 = *RT_REC(5, rs), l4 = *RT_REC(6, rs), h4 = *RT_REC(3, rs);
                     const uint32_t pix = __float_as_uint(meta.y);
                     const uint32_t key = __float_as_uint(meta.z);
                     const int bounce = DIEL ? (__float_as_int(meta.w) & (kPoolInsideBit - 1)) : __float_as_int(meta.w);
@@ -228,20 +225,20 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                         write = false;
                         if (rayDegenerate(next)) { poolHandOver(a, pix); ended = true; }
                         else {
-                            rec->r0 = make_float4(next.origin.x, next.origin.y, next.origin.z, next.direction.x);
-                            rec->r1 = make_float4(next.direction.y, next.direction.z, next.invDir.x, next.invDir.y);
-                            *reinterpret_cast<float4*>(&rec->invz) = make_float4(next.invDir.z, meta.y, meta.z, __int_as_float((bounce + 1) | (insideGlass ? kPoolInsideBit : 0)));
-                            rec->energy = make_float4(energy.x, energy.y, energy.z, 0.f);
+                            *RT_REC(0, rs) = make_float4(next.origin.x, next.origin.y, next.origin.z, next.direction.x);
+                            *RT_REC(1, rs) = make_float4(next.direction.y, next.direction.z, next.invDir.x, next.invDir.y);
+                            *RT_REC(2, rs) = make_float4(next.invDir.z, meta.y, meta.z, __int_as_float((bounce + 1) | (insideGlass ? kPoolInsideBit : 0)));
+                            *RT_REC(5, rs) = make_float4(energy.x, energy.y, energy.z, 0.f);
                             if (__float_as_uint(L.x) != __float_as_uint(l4.x) || __float_as_uint(L.y) != __float_as_uint(l4.y) || __float_as_uint(L.z) != __float_as_uint(l4.z))
-                                rec->L = make_float4(L.x, L.y, L.z, 0.f);      // (most surfaces emit nothing: the sum keeps its bits)
+                                *RT_REC(6, rs) = make_float4(L.x, L.y, L.z, 0.f);      // (most surfaces emit nothing: the sum keeps its bits)
                             goOn = true;
                         }
                     }
                     if (write) {
-                        b.sampleL[rec->path] = make_float4(L.x, L.y, L.z, __int_as_float(bounce + 1));
+                        b.sampleL[RT_REC_PATH(rs)] = make_float4(L.x, L.y, L.z, __int_as_float(bounce + 1));
                         ended = true;
                     }
-                    if (ended) rec->inst = kPoolFresh;      // the record waits in the other queue for its next path
+                    if (ended) RT_REC_INST(rs) = kPoolFresh;      // the record waits in the other queue for its next path
                 }
             } else {
                 // ---- path ends (sky light, hand-over) and starts: queued records first, then record slots never used so far
@@ -256,16 +253,16 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                 if (s >= 0) {
                     ended = true;
                     if (lane < n) {
-                        PoolRec* rec = recs + s;
-                        const int32_t inst = rec->inst;
+                        const int rs = s;
+                        const int32_t inst = RT_REC_INST(rs);
                         if (inst == kPoolMiss) {
-                            const float4 meta = *reinterpret_cast<const float4*>(&rec->invz);
-                            const float4 r0 = rec->r0, r1 = rec->r1, e4 = rec->energy, l4 = rec->L;
+                            const float4 meta = *RT_REC(2, rs);
+                            const float4 r0 = *RT_REC(0, rs), r1 = *RT_REC(1, rs), e4 = *RT_REC(5, rs), l4 = *RT_REC(6, rs);
                             const int bounce = DIEL ? (__float_as_int(meta.w) & (kPoolInsideBit - 1)) : __float_as_int(meta.w);
                             V3 L = v3(l4.x, l4.y, l4.z) + v3(e4.x, e4.y, e4.z) * shadeMiss(sky, v3(r0.w, r1.x, r1.y));
-                            b.sampleL[rec->path] = make_float4(L.x, L.y, L.z, __int_as_float(bounce + 1));
+                            b.sampleL[RT_REC_PATH(rs)] = make_float4(L.x, L.y, L.z, __int_as_float(bounce + 1));
                         } else if (inst == kPoolUnsettled) {
-                            poolHandOver(a, rec->pix);
+                            poolHandOver(a, RT_REC_PIX(rs));
                         }
                     }
                 }
@@ -301,9 +298,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                         const uint32_t mine = (uint32_t)__popcll(me & laneBelow);
                         const unsigned long long p = base + mine;
                         if (noMoreWork) { }
-                        else if (p >= pathEnd) { recs[s].inst = kPoolFresh; fresh = true; }
+                        else if (p >= pathEnd) { RT_REC_INST(s) = kPoolFresh; fresh = true; }
                         else {
-                            PoolRec* rec = recs + s;
+                            const int rs = s;
                             uint32_t wItem = baseItem + mine;
                             int smp = baseSmp;
                             if (wItem >= b.nWork) { wItem -= b.nWork; smp++; }
@@ -318,18 +315,18 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                                     const Ray r = cameraRay(a.cb, pixelToNdc(x, jx, a.width), pixelToNdc(y, jy, a.height));
                                     if (rayDegenerate(r)) poolHandOver(a, pix);
                                     else {
-                                        rec->r0 = make_float4(r.origin.x, r.origin.y, r.origin.z, r.direction.x);
-                                        rec->r1 = make_float4(r.direction.y, r.direction.z, r.invDir.x, r.invDir.y);
-                                        *reinterpret_cast<float4*>(&rec->invz) = make_float4(r.invDir.z, __uint_as_float(pix), __uint_as_float(key), __int_as_float(0));
-                                        rec->path = (uint32_t)p;
-                                        rec->energy = make_float4(1.f, 1.f, 1.f, 0.f);
-                                        rec->L = make_float4(0.f, 0.f, 0.f, 0.f);
+                                        *RT_REC(0, rs) = make_float4(r.origin.x, r.origin.y, r.origin.z, r.direction.x);
+                                        *RT_REC(1, rs) = make_float4(r.direction.y, r.direction.z, r.invDir.x, r.invDir.y);
+                                        *RT_REC(2, rs) = make_float4(r.invDir.z, __uint_as_float(pix), __uint_as_float(key), __int_as_float(0));
+                                        RT_REC_PATH(rs) = (uint32_t)p;
+                                        *RT_REC(5, rs) = make_float4(1.f, 1.f, 1.f, 0.f);
+                                        *RT_REC(6, rs) = make_float4(0.f, 0.f, 0.f, 0.f);
                                         live = true;
                                     }
                                 }
                             }
                             if (live) goOn = true;
-                            else { rec->inst = kPoolFresh; fresh = true; }     // no such path: take another one next time
+                            else { RT_REC_INST(rs) = kPoolFresh; fresh = true; }     // no such path: take another one next time
                         }
                     }
                 } else if (kind == 1 && ended) fresh = true;          // ended at a surface: queued for a new path
@@ -355,8 +352,14 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             const int mine = __popcll(m & laneBelow);
             if (idleLane && mine < k) {
                 slot = rayQ[(rayHead + mine) & (kPoolQueue - 1)];
-                world = poolLoadRay(recs + slot);
-                if (DIEL) twoSided = (recs[slot].bounce & kPoolInsideBit) != 0;
+                {
+                    const float4 r0 = *RT_REC(0, slot), r1 = *RT_REC(1, slot);
+                    const float iz = RT_REC(2, slot)->x;
+                    world.origin = v3(r0.x, r0.y, r0.z);
+                    world.direction = v3(r0.w, r1.x, r1.y);
+                    world.invDir = v3(r1.z, r1.w, iz);
+                }
+                if (DIEL) twoSided = (RT_REC_BOUNCE(slot) & kPoolInsideBit) != 0;
                 cur = world;
                 best.t = RT_INF; best.u = best.v = 0; best.inst = -1; best.tri = -1;
                 secondT = RT_INF; bestNear = 0.0f;
@@ -385,6 +388,11 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
 #undef RT_WORLD_RAY
 #undef RT_REDO
 #undef RT_STAT
+#undef RT_REC
+#undef RT_REC_INST
+#undef RT_REC_PATH
+#undef RT_REC_PIX
+#undef RT_REC_BOUNCE
     if (STATS) {
         for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(deepest, off, 64); deepest = o > deepest ? o : deepest; }
         if (lane == 0) {

@@ -16,7 +16,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = os.environ.get("RTAMD_PMC_KERNEL", "rt::kPool(")
+KERNEL = os.environ.get("RTAMD_PMC_KERNEL", "rt::kPool<")
 
 
 def summarise(tag):
@@ -40,7 +40,7 @@ def summarise(tag):
         cycles = d["GRBM_GUI_ACTIVE"] / 8.0
         der["simd_valu_issue_frac"] = d["SQ_ACTIVE_INST_VALU"] / (1024.0 * cycles / 4.0)
         der["l1_accesses_per_cu_cycle"] = d.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / (256.0 * cycles)
-    der["note"] = ("one launch of " + KERNEL.rstrip("(") + " (bench.py --steps 1 --warmup 0); separate rocprofv3 --pmc passes; "
+    der["note"] = ("one launch of " + KERNEL.rstrip("(<") + " (bench.py --steps 1 --warmup 0); separate rocprofv3 --pmc passes; "
                    "FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as read")
     d["derived"] = der
     return d
