@@ -1,7 +1,7 @@
 """Compile the native libraries in-tree.
 
   raytracing_amd/lib/librtamd.so       HIP kernels + C ABI (hipcc, gfx950 only)
-  raytracing_amd/lib/librtamd_host.so  host-side scene producers (g++, CPU only)
+  raytracing_amd/lib/librtamd_host.so  host-side helpers + the restated reference scene producers of tests/producers (g++, CPU only)
   oracle/_build/librt_oracle.so        CPU oracle (g++; test infrastructure)
 
 Run as `python -m raytracing_amd.build` or through `__graft_entry__.build()`.
@@ -49,9 +49,15 @@ def build_device(force=False):
 
 
 def build_host(force=False):
+    """librtamd_host.so: the package's own host helpers (mesh sources, image codecs, SAH tree writer,
+    camera, scene file: raytracing_amd/csrc/host) together with the restated reference producers that
+    only tests, fixtures and synthetic bench inputs use (tests/producers)."""
     hdir = os.path.join(CSRC, "host")
+    pdir = os.path.join(ROOT, "tests", "producers")
     srcs = sorted(os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".cpp"))
-    deps = srcs + [os.path.join(hdir, "host_internal.h"), os.path.join(INC, "rtamd.h"), os.path.join(INC, "rtamd_host.h")]
+    srcs += sorted(os.path.join(pdir, f) for f in os.listdir(pdir) if f.endswith(".cpp"))
+    deps = srcs + [os.path.join(hdir, "host_internal.h"), os.path.join(CSRC, "wide_bvh.h"), os.path.join(INC, "rtamd.h"),
+                   os.path.join(INC, "rtamd_host.h")]
     out = os.path.join(LIB, "librtamd_host.so")
     if force or _newer(out, deps):
         os.makedirs(LIB, exist_ok=True)

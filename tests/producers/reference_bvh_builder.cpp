@@ -11,7 +11,11 @@
 //   * ranges of <= 32 points are insertion-sorted on one axis and cut into runs of
 //     four (:359-394);
 //   * bounds come only from Refit (:560-602), bottom-up over node indices.
-// Also provides a binned-SAH builder that emits the same node format.
+//
+// TEST / FIXTURE INFRASTRUCTURE, not product code: a function-by-function C++ restatement of the
+// reference's C# builder, kept so that scenes can be produced without Unity exactly as the reference
+// would produce them.  The builders the library itself uses are raytracing_amd/csrc/wide_bvh.h
+// (binned SAH) and raytracing_amd/csrc/tlas_build.hip (GPU LBVH).
 
 #include <algorithm>
 #include <cfloat>
@@ -399,150 +403,6 @@ int bvhBuildJobs(rtamd_point_and_index* points, const rtamd_aabb* aabbs, int n, 
     }
     refit(nodes, aabbs, 1, minBranchNodeIndex);
     if (branchCountOut) *branchCountOut = branchCount;
-    return RTAMD_OK;
-}
-
-// ---------------------------------------------------------------------------
-// Binned SAH builder (same node format).  A binary split is chosen by 16-bin SAH
-// on the centroid bounds' widest axes (all three tried); a 4-wide node is made by
-// splitting the cheaper... larger-surface child again, until four children or all
-// children are leaves of <= 4 primitives.
-// ---------------------------------------------------------------------------
-namespace {
-
-struct SahPrim { Aabb box; float3 c; int index; };
-
-inline float halfArea(const Aabb& b) {
-    float dx = b.Max.x - b.Min.x, dy = b.Max.y - b.Min.y, dz = b.Max.z - b.Min.z;
-    if (dx < 0 || dy < 0 || dz < 0) return 0.f;
-    return dx * dy + dy * dz + dz * dx;
-}
-inline void grow(Aabb& a, const Aabb& b) { a.Min = min3(a.Min, b.Min); a.Max = max3(a.Max, b.Max); }
-
-struct SahBuilder {
-    std::vector<SahPrim>& prims;
-    rtamd_node* nodes; int capacity; int freeNode = 2; bool failed = false;
-
-    // split [lo,hi) into two; returns mid (lo < mid < hi)
-    int split(int lo, int hi) {
-        int n = hi - lo;
-        Aabb cb = kEmptyAabb;
-        for (int i = lo; i < hi; i++) include(cb, prims[i].c);
-        constexpr int NB = 16;
-        float bestCost = FLT_MAX; int bestAxis = -1, bestBin = -1;
-        for (int axis = 0; axis < 3; axis++) {
-            float cmin = comp(cb.Min, axis), cmax = comp(cb.Max, axis);
-            if (!(cmax > cmin)) continue;
-            float scale = NB / (cmax - cmin);
-            Aabb bb[NB]; int cnt[NB];
-            for (int b = 0; b < NB; b++) { bb[b] = kEmptyAabb; cnt[b] = 0; }
-            for (int i = lo; i < hi; i++) {
-                int b = (int)((comp(prims[i].c, axis) - cmin) * scale);
-                if (b < 0) b = 0; if (b >= NB) b = NB - 1;
-                grow(bb[b], prims[i].box); cnt[b]++;
-            }
-            float rightArea[NB]; int rightCnt[NB];
-            Aabb acc = kEmptyAabb; int c = 0;
-            for (int b = NB - 1; b > 0; b--) { grow(acc, bb[b]); c += cnt[b]; rightArea[b] = halfArea(acc); rightCnt[b] = c; }
-            acc = kEmptyAabb; c = 0;
-            for (int b = 0; b < NB - 1; b++) {
-                grow(acc, bb[b]); c += cnt[b];
-                if (c == 0 || rightCnt[b + 1] == 0) continue;
-                // leaves hold up to 4 primitives: cost in units of 4-prim groups
-                float cost = halfArea(acc) * (float)((c + 3) / 4) + rightArea[b + 1] * (float)((rightCnt[b + 1] + 3) / 4);
-                if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
-            }
-        }
-        if (bestAxis < 0) {
-            return lo + n / 2;   // all centroids coincide
-        }
-        float cmin = comp(cb.Min, bestAxis), cmax = comp(cb.Max, bestAxis);
-        float scale = 16 / (cmax - cmin);
-        auto it = std::partition(prims.begin() + lo, prims.begin() + hi, [&](const SahPrim& p) {
-            int b = (int)((comp(p.c, bestAxis) - cmin) * scale);
-            if (b < 0) b = 0; if (b >= 16) b = 15;
-            return b <= bestBin;
-        });
-        int mid = (int)(it - prims.begin());
-        if (mid == lo || mid == hi) mid = lo + n / 2;
-        return mid;
-    }
-
-    float rangeArea(int lo, int hi) {
-        Aabb b = kEmptyAabb;
-        for (int i = lo; i < hi; i++) grow(b, prims[i].box);
-        return halfArea(b);
-    }
-
-    // fills node `ni` (already allocated) for prims [lo,hi), n > 4
-    void buildNode(int ni, int lo, int hi) {
-        struct Seg { int lo, hi; };
-        Seg segs[4]; int ns = 1;
-        segs[0] = {lo, hi};
-        while (ns < 4) {
-            // split the segment with the largest area * count among those with > 4 prims
-            int pick = -1; float best = -1.f;
-            for (int s = 0; s < ns; s++) {
-                int n = segs[s].hi - segs[s].lo;
-                if (n <= 4) continue;
-                float score = rangeArea(segs[s].lo, segs[s].hi) * (float)n;
-                if (score > best) { best = score; pick = s; }
-            }
-            if (pick < 0) break;
-            int mid = split(segs[pick].lo, segs[pick].hi);
-            Seg a = {segs[pick].lo, mid}, b = {mid, segs[pick].hi};
-            for (int s = ns; s > pick + 1; s--) segs[s] = segs[s - 1];
-            segs[pick] = a; segs[pick + 1] = b; ns++;
-        }
-        int data[4] = {0, 0, 0, 0};
-        int child[4];
-        for (int s = 0; s < ns; s++) {
-            if (freeNode >= capacity) { failed = true; return; }
-            child[s] = freeNode++;
-            data[s] = child[s];
-        }
-        std::memcpy(nodes[ni].Data, data, sizeof(data));
-        nodes[ni].Flags = 0;
-        for (int s = 0; s < ns; s++) {
-            int n = segs[s].hi - segs[s].lo;
-            if (n <= 4) {
-                rtamd_node& leaf = nodes[child[s]];
-                leaf.Flags = 1;
-                for (int k = 0; k < 4; k++) leaf.Data[k] = k < n ? prims[segs[s].lo + k].index : -1;
-            } else {
-                buildNode(child[s], segs[s].lo, segs[s].hi);
-                if (failed) return;
-            }
-        }
-    }
-};
-
-}  // namespace
-
-int bvhBuildSah(const rtamd_aabb* aabbs, int n, rtamd_node* nodes, int capacity, int* nodeCount) {
-    if (capacity < 2 || n < 0) return RTAMD_ERR_INVALID_ARG;
-    setNodeEmpty(nodes[0]);
-    if (n == 0) { setNodeEmpty(nodes[1]); *nodeCount = 2; return RTAMD_OK; }
-    std::vector<SahPrim> prims(n);
-    for (int i = 0; i < n; i++) {
-        const rtamd_aabb& a = aabbs[i];
-        prims[i].box = {{a.Min[0], a.Min[1], a.Min[2]}, {a.Max[0], a.Max[1], a.Max[2]}};
-        prims[i].c = {(a.Min[0] + a.Max[0]) * 0.5f, (a.Min[1] + a.Max[1]) * 0.5f, (a.Min[2] + a.Max[2]) * 0.5f};
-        prims[i].index = i;
-    }
-    SahBuilder b{prims, nodes, capacity};
-    if (n <= 4) {
-        if (capacity < 3) return RTAMD_ERR_INVALID_ARG;
-        nodes[1].Flags = 0; nodes[1].Data[0] = 2; nodes[1].Data[1] = nodes[1].Data[2] = nodes[1].Data[3] = 0;
-        nodes[2].Flags = 1;
-        for (int k = 0; k < 4; k++) nodes[2].Data[k] = k < n ? k : -1;
-        b.freeNode = 3;
-    } else {
-        b.buildNode(1, 0, n);
-        if (b.failed) return RTAMD_ERR_BAD_INDEX;
-    }
-    *nodeCount = b.freeNode;
-    refit(nodes, aabbs, 1, b.freeNode - 1);
     return RTAMD_OK;
 }
 
