@@ -22,3 +22,9 @@ for f in glob.glob("gpurun_out/pmc_stream/**/*counter_collection.csv", recursive
 for k, v in sorted(acc.items()):
     print(k, [f"{x:.4g}" for x in v])
 PY
+# streaming / gather ceilings of the cache levels, and the per-phase lane statistics of the path-pool kernel
+timeout -k 10 120 tools/bin/l2_stream > gpurun_out/stream.json
+( RTAMD_STATS=1 timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-counters --no-secondary --steps 1 --warmup 0 2>&1 >/dev/null | grep stats | sed 's/^/mesh 1080p 256spp: /'
+  RTAMD_STATS=1 timeout -k 10 200 python3 bench.py --workload spheres --no-cpu-baseline --no-counters --steps 1 --warmup 0 2>&1 >/dev/null | grep stats | sed 's/^/spheres 1080p 64spp: /'
+  RTAMD_STATS=1 timeout -k 10 200 python3 bench.py --workload instanced --no-cpu-baseline --no-counters --steps 1 --warmup 0 2>&1 >/dev/null | grep stats | sed 's/^/instanced 1080p 64spp: /' ) > gpurun_out/phase_lanes.txt
+cat gpurun_out/stream.json gpurun_out/phase_lanes.txt
