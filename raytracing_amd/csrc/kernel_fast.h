@@ -314,12 +314,18 @@ struct FastSceneHost {
 
 // ------------------------------------------------------------------ kernel ---
 
-constexpr int kBlockThreads = 1024;  // one workgroup per CU: its 16 waves share one LDS copy of the hot nodes
+#ifndef RT_BLOCK_THREADS
+#define RT_BLOCK_THREADS 1024
+#endif
+constexpr int kBlockThreads = RT_BLOCK_THREADS;  // one workgroup per CU: its 16 waves share one LDS copy of the hot nodes
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
 #endif
 constexpr int kLdsStack = 24;        // stack entries per lane, all in LDS: [entry][thread], conflict-free (96 KiB)
-constexpr int kHotNodes = 448;       // nodes every workgroup keeps in LDS (63 KiB): the TLAS and the top of the BLAS trees
+#ifndef RT_HOT_NODES
+#define RT_HOT_NODES 448
+#endif
+constexpr int kHotNodes = RT_HOT_NODES;       // nodes every workgroup keeps in LDS (63 KiB): the TLAS and the top of the BLAS trees
 constexpr int kHotStride = 9;        // float4 per node in LDS: 144 bytes, so that piece j of 16 different nodes falls on 16 different bank groups
 constexpr int kModeRef = 0, kModePt = 1, kModePrimary = 2;
 constexpr int kNoInstance = -(1 << 24);
@@ -641,6 +647,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
 #undef RT_CAN_REFILL
     }
 #undef RT_PUSH
+#undef RT_PUSH_IF
 #undef RT_POP
 #undef RT_MAKE_ROOM
 #undef RT_SPILL_AT

@@ -41,7 +41,10 @@ constexpr int32_t kPoolMiss = -1, kPoolUnsettled = -3, kPoolFresh = -4;
 constexpr int kPoolSlots = 128;      // paths per wave (record slots); 144 .. 192 gain 1-2 % on a scene that fits the caches and lose 2-4 % on one that does not
 constexpr int kPoolQueue = 128;      // entries per queue (power of two >= kPoolSlots; a slot index fits a byte)
 constexpr int kPoolChunk = 256;      // path indices a wave takes from the batch at a time (fewer when the batch is small)
-constexpr int kPoolHotNodes = 376;   // LDS: 96 KiB stacks + 6 KiB queues + 53 KiB nodes
+#ifndef RT_POOL_HOT_NODES
+#define RT_POOL_HOT_NODES 376
+#endif
+constexpr int kPoolHotNodes = RT_POOL_HOT_NODES;   // LDS: 96 KiB stacks + 6 KiB queues + 53 KiB nodes
 
 struct PoolBatch {
     PoolRec* recs;                // [waves of the grid][kPoolSlots]
@@ -382,6 +385,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
 #undef RT_CAN_REFILL
     }
 #undef RT_PUSH
+#undef RT_PUSH_IF
 #undef RT_POP
 #undef RT_MAKE_ROOM
 #undef RT_SPILL_AT
