@@ -71,6 +71,14 @@ __device__ __forceinline__ bool poolPixel(const FastScene& sc, const RenderArgs&
     return x < a.width && y < a.height && x >= a.tileX && y >= a.tileY && x < a.tileX + a.tileW && y < a.tileY + a.tileH;
 }
 
+// A finished sample: written once, read once by kPoolSum after the launch; stored past the caches'
+// usual policy so that 16 bytes per path do not push BVH nodes and path records out of them.
+__device__ __forceinline__ void poolStoreSample(float4* dst, V3 L, int segments) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = {L.x, L.y, L.z, __int_as_float(segments)};
+    __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst));
+}
+
 __device__ __forceinline__ void poolHandOver(const RenderArgs& a, uint32_t p) {
     const uint32_t bit = 1u << (p & 31u);
     const uint32_t old = atomicOr(a.redoMask + (p >> 5), bit);
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                         }
                     }
                     if (write) {
-                        b.sampleL[RT_REC_PATH(rs)] = make_float4(L.x, L.y, L.z, __int_as_float(bounce + 1));
+                        poolStoreSample(b.sampleL + RT_REC_PATH(rs), L, bounce + 1);
                         ended = true;
                     }
                     if (ended) RT_REC_INST(rs) = kPoolFresh;      // the record waits in the other queue for its next path
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                             const float4 r0 = *RT_REC(0, rs), r1 = *RT_REC(1, rs), e4 = *RT_REC(5, rs), l4 = *RT_REC(6, rs);
                             const int bounce = DIEL ? (__float_as_int(meta.w) & (kPoolInsideBit - 1)) : __float_as_int(meta.w);
                             V3 L = v3(l4.x, l4.y, l4.z) + v3(e4.x, e4.y, e4.z) * shadeMiss(sky, v3(r0.w, r1.x, r1.y));
-                            b.sampleL[RT_REC_PATH(rs)] = make_float4(L.x, L.y, L.z, __int_as_float(bounce + 1));
+                            poolStoreSample(b.sampleL + RT_REC_PATH(rs), L, bounce + 1);
                         } else if (inst == kPoolUnsettled) {
                             poolHandOver(a, RT_REC_PIX(rs));
                         }
