@@ -71,6 +71,11 @@ __device__ __forceinline__ bool poolPixel(const FastScene& sc, const RenderArgs&
     return x < a.width && y < a.height && x >= a.tileX && y >= a.tileY && x < a.tileX + a.tileW && y < a.tileY + a.tileH;
 }
 
+// Path records keep the default cache policy: they are re-read tens of microseconds after they were written,
+// and moving them with the non-temporal policy (to leave L1 / L2 to the BVH) was measured 22-35 % slower.
+__device__ __forceinline__ float4 recLoad(const float4* p) { return *p; }
+__device__ __forceinline__ void recStore(float4* p, float4 v) { *p = v; }
+
 // A finished sample: written once, read once by kPoolSum after the launch; stored past the caches'
 // usual policy so that 16 bytes per path do not push BVH nodes and path records out of them.
 __device__ __forceinline__ void poolStoreSample(float4* dst, V3 L, int segments) {
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             if (fin) {
                 const int rs = slot;
                 if (toHit) {
-                    *RT_REC(3, rs) = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
+                    recStore(RT_REC(3, rs), make_float4(best.t, best.u, best.v, __int_as_float(best.tri)));
                     RT_REC_INST(rs) = best.inst;
                     hitQ[(hitTail + __popcll(mh & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)slot;
                 } else {
@@ -214,8 +219,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                 if (s >= 0) {
                     const int rs = s;
                     const int32_t inst = RT_REC_INST(rs);
-                    const float4 meta = *RT_REC(2, rs);
-                    const float4 r0 = *RT_REC(0, rs), r1 = *RT_REC(1, rs), e4 = *RT_REC(5, rs), l4 = *RT_REC(6, rs), h4 = *RT_REC(3, rs);
+                    const float4 meta = recLoad(RT_REC(2, rs));
+                    const float4 r0 = recLoad(RT_REC(0, rs)), r1 = recLoad(RT_REC(1, rs)), e4 = recLoad(RT_REC(5, rs)), l4 = recLoad(RT_REC(6, rs)), h4 = recLoad(RT_REC(3, rs));
                     const uint32_t pix = __float_as_uint(meta.y);
                     const uint32_t key = __float_as_uint(meta.z);
                     const int bounce = DIEL ? (__float_as_int(meta.w) & (kPoolInsideBit - 1)) : __float_as_int(meta.w);
@@ -236,12 +241,12 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                         write = false;
                         if (rayDegenerate(next)) { poolHandOver(a, pix); ended = true; }
                         else {
-                            *RT_REC(0, rs) = make_float4(next.origin.x, next.origin.y, next.origin.z, next.direction.x);
-                            *RT_REC(1, rs) = make_float4(next.direction.y, next.direction.z, next.invDir.x, next.invDir.y);
-                            *RT_REC(2, rs) = make_float4(next.invDir.z, meta.y, meta.z, __int_as_float((bounce + 1) | (insideGlass ? kPoolInsideBit : 0)));
-                            *RT_REC(5, rs) = make_float4(energy.x, energy.y, energy.z, 0.f);
+                            recStore(RT_REC(0, rs), make_float4(next.origin.x, next.origin.y, next.origin.z, next.direction.x));
+                            recStore(RT_REC(1, rs), make_float4(next.direction.y, next.direction.z, next.invDir.x, next.invDir.y));
+                            recStore(RT_REC(2, rs), make_float4(next.invDir.z, meta.y, meta.z, __int_as_float((bounce + 1) | (insideGlass ? kPoolInsideBit : 0))));
+                            recStore(RT_REC(5, rs), make_float4(energy.x, energy.y, energy.z, 0.f));
                             if (__float_as_uint(L.x) != __float_as_uint(l4.x) || __float_as_uint(L.y) != __float_as_uint(l4.y) || __float_as_uint(L.z) != __float_as_uint(l4.z))
-                                *RT_REC(6, rs) = make_float4(L.x, L.y, L.z, 0.f);      // (most surfaces emit nothing: the sum keeps its bits)
+                                recStore(RT_REC(6, rs), make_float4(L.x, L.y, L.z, 0.f));      // (most surfaces emit nothing: the sum keeps its bits)
                             goOn = true;
                         }
                     }
@@ -267,8 +272,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                         const int rs = s;
                         const int32_t inst = RT_REC_INST(rs);
                         if (inst == kPoolMiss) {
-                            const float4 meta = *RT_REC(2, rs);
-                            const float4 r0 = *RT_REC(0, rs), r1 = *RT_REC(1, rs), e4 = *RT_REC(5, rs), l4 = *RT_REC(6, rs);
+                            const float4 meta = recLoad(RT_REC(2, rs));
+                            const float4 r0 = recLoad(RT_REC(0, rs)), r1 = recLoad(RT_REC(1, rs)), e4 = recLoad(RT_REC(5, rs)), l4 = recLoad(RT_REC(6, rs));
                             const int bounce = DIEL ? (__float_as_int(meta.w) & (kPoolInsideBit - 1)) : __float_as_int(meta.w);
                             V3 L = v3(l4.x, l4.y, l4.z) + v3(e4.x, e4.y, e4.z) * shadeMiss(sky, v3(r0.w, r1.x, r1.y));
                             poolStoreSample(b.sampleL + RT_REC_PATH(rs), L, bounce + 1);
@@ -326,12 +331,12 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                                     const Ray r = cameraRay(a.cb, pixelToNdc(x, jx, a.width), pixelToNdc(y, jy, a.height));
                                     if (rayDegenerate(r)) poolHandOver(a, pix);
                                     else {
-                                        *RT_REC(0, rs) = make_float4(r.origin.x, r.origin.y, r.origin.z, r.direction.x);
-                                        *RT_REC(1, rs) = make_float4(r.direction.y, r.direction.z, r.invDir.x, r.invDir.y);
-                                        *RT_REC(2, rs) = make_float4(r.invDir.z, __uint_as_float(pix), __uint_as_float(key), __int_as_float(0));
+                                        recStore(RT_REC(0, rs), make_float4(r.origin.x, r.origin.y, r.origin.z, r.direction.x));
+                                        recStore(RT_REC(1, rs), make_float4(r.direction.y, r.direction.z, r.invDir.x, r.invDir.y));
+                                        recStore(RT_REC(2, rs), make_float4(r.invDir.z, __uint_as_float(pix), __uint_as_float(key), __int_as_float(0)));
                                         RT_REC_PATH(rs) = (uint32_t)p;
-                                        *RT_REC(5, rs) = make_float4(1.f, 1.f, 1.f, 0.f);
-                                        *RT_REC(6, rs) = make_float4(0.f, 0.f, 0.f, 0.f);
+                                        recStore(RT_REC(5, rs), make_float4(1.f, 1.f, 1.f, 0.f));
+                                        recStore(RT_REC(6, rs), make_float4(0.f, 0.f, 0.f, 0.f));
                                         live = true;
                                     }
                                 }
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             if (idleLane && mine < k) {
                 slot = rayQ[(rayHead + mine) & (kPoolQueue - 1)];
                 {
-                    const float4 r0 = *RT_REC(0, slot), r1 = *RT_REC(1, slot);
+                    const float4 r0 = recLoad(RT_REC(0, slot)), r1 = recLoad(RT_REC(1, slot));
                     const float iz = RT_REC(2, slot)->x;
                     world.origin = v3(r0.x, r0.y, r0.z);
                     world.direction = v3(r0.w, r1.x, r1.y);
