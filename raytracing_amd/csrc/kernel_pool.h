@@ -20,22 +20,18 @@
 
 namespace rt {
 
-struct alignas(128) PoolRec {
-    float4 r0;            // origin.xyz, direction.x
-    float4 r1;            // direction.yz, invDir.xy
-    float invz;           // invDir.z
-    uint32_t pix;         // y * width + x
-    uint32_t key;         // RNG key of (seed, pixel, sample)
-    int32_t bounce;       // index of the segment the ray belongs to
-    float4 hit;           // t, u, v, triangle rank (bits)
-    int32_t inst;         // instance rank; kPoolMiss; kPoolUnsettled: hand the pixel over; kPoolFresh: no path yet
-    uint32_t path;        // index of the path in the batch's sample buffer
-    int32_t pad0[2];
-    float4 energy;        // throughput
-    float4 L;             // radiance gathered so far
-    float4 pad1;
-};
-static_assert(sizeof(PoolRec) == 128, "one record per 128-byte line");
+// A path's record: a 64-byte hot part (what traversal, publishing and refilling touch) and a 32-byte cold part.
+// Per wave the hot parts of its kPoolSlots slots come first, then the cold parts, so two hot records share a
+// 128-byte line and the record stream through L2 and the fabric is 96 instead of 128 bytes per path.
+//   hot 0   origin.xyz, direction.x
+//   hot 1   direction.yz, invDir.xy
+//   hot 2   invDir.z, bounce (bit 16: inside glass), RNG key, state
+//           state: instance rank of the hit; kPoolMiss; kPoolUnsettled: hand the pixel over; kPoolFresh: no path
+//   hot 3   t, u, v, triangle rank (bits)
+//   cold 0  throughput.xyz, index of the path in the batch's sample buffer
+//   cold 1  radiance gathered so far .xyz (read and written only where a surface emits or the path ends), pixel
+struct alignas(32) PoolRec { float4 piece[6]; };
+static_assert(sizeof(PoolRec) == 96, "64 hot + 32 cold bytes per path");
 
 constexpr int32_t kPoolMiss = -1, kPoolUnsettled = -3, kPoolFresh = -4;
 constexpr int kPoolSlots = 128;      // paths per wave (record slots); 144 .. 192 gain 1-2 % on a scene that fits the caches and lose 2-4 % on one that does not
@@ -122,14 +118,14 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
     uint8_t* const hitQ = ldsQueues[wave][1];     // paths whose ray hit a surface: to be shaded and scattered
     uint8_t* const endQ = ldsQueues[wave][2];     // paths whose ray left the scene, that ended at a surface, that cannot be settled here,
                                                   // and records without a path: each gets (its sky light and) the next path of the batch
-    // The wave's records: one 128-byte line per slot, 8 pieces of 16 bytes (r0, r1, meta, hit, aux, energy, L, unused; see
-    // PoolRec).  (Piece-major storage, [piece][slot], was measured 9-22 % slower: every line then holds parts of 8 paths.)
-    float4* const recBase = reinterpret_cast<float4*>(b.recs + ((size_t)blockIdx.x * (kBlockThreads / 64) + wave) * kPoolSlots);
-#define RT_REC(piece, sl) (recBase + (sl) * 8 + (piece))
-#define RT_REC_INST(sl) (*reinterpret_cast<int32_t*>(RT_REC(4, sl)))
-#define RT_REC_PATH(sl) (reinterpret_cast<uint32_t*>(RT_REC(4, sl))[1])
-#define RT_REC_PIX(sl) (reinterpret_cast<uint32_t*>(RT_REC(2, sl))[1])
-#define RT_REC_BOUNCE(sl) (reinterpret_cast<int32_t*>(RT_REC(2, sl))[3])
+    // the wave's records (see PoolRec): hot parts [slot][4 pieces], then cold parts [slot][2 pieces]
+    float4* const recHot = reinterpret_cast<float4*>(b.recs + ((size_t)blockIdx.x * (kBlockThreads / 64) + wave) * kPoolSlots);
+    float4* const recCold = recHot + kPoolSlots * 4;
+#define RT_HOT(piece, sl) (recHot + (sl) * 4 + (piece))
+#define RT_COLD(piece, sl) (recCold + (sl) * 2 + (piece))
+#define RT_REC_STATE(sl) (reinterpret_cast<int32_t*>(RT_HOT(2, sl))[3])
+#define RT_REC_BOUNCE(sl) (reinterpret_cast<int32_t*>(RT_HOT(2, sl))[1])
+#define RT_REC_PIX(sl) (reinterpret_cast<uint32_t*>(RT_COLD(1, sl))[3])
     const unsigned long long totalPaths = (unsigned long long)b.nWork * (unsigned long long)b.nSamples;
     const unsigned long long laneBelow = (1ull << lane) - 1ull;
 
@@ -180,11 +176,11 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             if (fin) {
                 const int rs = slot;
                 if (toHit) {
-                    recStore(RT_REC(3, rs), make_float4(best.t, best.u, best.v, __int_as_float(best.tri)));
-                    RT_REC_INST(rs) = best.inst;
+                    recStore(RT_HOT(3, rs), make_float4(best.t, best.u, best.v, __int_as_float(best.tri)));
+                    RT_REC_STATE(rs) = best.inst;
                     hitQ[(hitTail + __popcll(mh & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)slot;
                 } else {
-                    RT_REC_INST(rs) = (unsettled || amb) ? kPoolUnsettled : kPoolMiss;
+                    RT_REC_STATE(rs) = (unsettled || amb) ? kPoolUnsettled : kPoolMiss;
                     endQ[(endTail + __popcll(me & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)slot;
                 }
                 slot = -1;
@@ -218,43 +214,50 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                 RT_STAT(0, s >= 0);
                 if (s >= 0) {
                     const int rs = s;
-                    const int32_t inst = RT_REC_INST(rs);
-                    const float4 meta = recLoad(RT_REC(2, rs));
-                    const float4 r0 = recLoad(RT_REC(0, rs)), r1 = recLoad(RT_REC(1, rs)), e4 = recLoad(RT_REC(5, rs)), l4 = recLoad(RT_REC(6, rs)), h4 = recLoad(RT_REC(3, rs));
-                    const uint32_t pix = __float_as_uint(meta.y);
+                    const float4 meta = recLoad(RT_HOT(2, rs));
+                    const float4 r0 = recLoad(RT_HOT(0, rs)), r1 = recLoad(RT_HOT(1, rs)), h4 = recLoad(RT_HOT(3, rs)), e4 = recLoad(RT_COLD(0, rs));
+                    const int32_t inst = __float_as_int(meta.w);
                     const uint32_t key = __float_as_uint(meta.z);
-                    const int bounce = DIEL ? (__float_as_int(meta.w) & (kPoolInsideBit - 1)) : __float_as_int(meta.w);
-                    bool insideGlass = DIEL && (__float_as_int(meta.w) & kPoolInsideBit) != 0;
+                    const int bounce = DIEL ? (__float_as_int(meta.y) & (kPoolInsideBit - 1)) : __float_as_int(meta.y);
+                    bool insideGlass = DIEL && (__float_as_int(meta.y) & kPoolInsideBit) != 0;
                     Ray w;
                     w.origin = v3(r0.x, r0.y, r0.z);
                     w.direction = v3(r0.w, r1.x, r1.y);
                     w.invDir = v3(r1.z, r1.w, meta.x);
-                    V3 energy = v3(e4.x, e4.y, e4.z), L = v3(l4.x, l4.y, l4.z);
+                    V3 energy = v3(e4.x, e4.y, e4.z);
                     FastHit h;
                     h.t = h4.x; h.u = h4.y; h.v = h4.z; h.inst = inst; h.tri = __float_as_int(h4.w);
                     const Surf sf = resolveHit(sc, w, h);
-                    L = L + energy * sf.emission;
+                    // light picked up here: most surfaces emit nothing, and then the radiance word is neither read nor
+                    // written (adding a zero leaves its bits; a NaN contribution compares unequal to 0 and is added)
+                    const V3 gain = energy * sf.emission;
+                    const bool lit = gain.x != 0.0f || gain.y != 0.0f || gain.z != 0.0f;
                     V3 org, dir;
                     bool write = true;
                     if (bounce < a.maxBounces && scatterSurface<DIEL>(sf, w.direction, key, (uint32_t)bounce, energy, org, dir, insideGlass)) {
                         const Ray next = makeRay(org, dir);
                         write = false;
-                        if (rayDegenerate(next)) { poolHandOver(a, pix); ended = true; }
+                        if (rayDegenerate(next)) { poolHandOver(a, RT_REC_PIX(rs)); ended = true; }
                         else {
-                            recStore(RT_REC(0, rs), make_float4(next.origin.x, next.origin.y, next.origin.z, next.direction.x));
-                            recStore(RT_REC(1, rs), make_float4(next.direction.y, next.direction.z, next.invDir.x, next.invDir.y));
-                            recStore(RT_REC(2, rs), make_float4(next.invDir.z, meta.y, meta.z, __int_as_float((bounce + 1) | (insideGlass ? kPoolInsideBit : 0))));
-                            recStore(RT_REC(5, rs), make_float4(energy.x, energy.y, energy.z, 0.f));
-                            if (__float_as_uint(L.x) != __float_as_uint(l4.x) || __float_as_uint(L.y) != __float_as_uint(l4.y) || __float_as_uint(L.z) != __float_as_uint(l4.z))
-                                recStore(RT_REC(6, rs), make_float4(L.x, L.y, L.z, 0.f));      // (most surfaces emit nothing: the sum keeps its bits)
+                            recStore(RT_HOT(0, rs), make_float4(next.origin.x, next.origin.y, next.origin.z, next.direction.x));
+                            recStore(RT_HOT(1, rs), make_float4(next.direction.y, next.direction.z, next.invDir.x, next.invDir.y));
+                            recStore(RT_HOT(2, rs), make_float4(next.invDir.z, __int_as_float((bounce + 1) | (insideGlass ? kPoolInsideBit : 0)), meta.z, meta.w));
+                            recStore(RT_COLD(0, rs), make_float4(energy.x, energy.y, energy.z, e4.w));
+                            if (lit) {
+                                const float4 l4 = recLoad(RT_COLD(1, rs));
+                                const V3 L = v3(l4.x, l4.y, l4.z) + gain;
+                                recStore(RT_COLD(1, rs), make_float4(L.x, L.y, L.z, l4.w));
+                            }
                             goOn = true;
                         }
                     }
                     if (write) {
-                        poolStoreSample(b.sampleL + RT_REC_PATH(rs), L, bounce + 1);
+                        const float4 l4 = recLoad(RT_COLD(1, rs));
+                        const V3 L = v3(l4.x, l4.y, l4.z) + gain;
+                        poolStoreSample(b.sampleL + __float_as_uint(e4.w), L, bounce + 1);
                         ended = true;
                     }
-                    if (ended) RT_REC_INST(rs) = kPoolFresh;      // the record waits in the other queue for its next path
+                    if (ended) RT_REC_STATE(rs) = kPoolFresh;      // the record waits in the other queue for its next path
                 }
             } else {
                 // ---- path ends (sky light, hand-over) and starts: queued records first, then record slots never used so far
@@ -270,13 +273,13 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                     ended = true;
                     if (lane < n) {
                         const int rs = s;
-                        const int32_t inst = RT_REC_INST(rs);
+                        const float4 meta = recLoad(RT_HOT(2, rs));
+                        const int32_t inst = __float_as_int(meta.w);
                         if (inst == kPoolMiss) {
-                            const float4 meta = recLoad(RT_REC(2, rs));
-                            const float4 r0 = recLoad(RT_REC(0, rs)), r1 = recLoad(RT_REC(1, rs)), e4 = recLoad(RT_REC(5, rs)), l4 = recLoad(RT_REC(6, rs));
-                            const int bounce = DIEL ? (__float_as_int(meta.w) & (kPoolInsideBit - 1)) : __float_as_int(meta.w);
+                            const float4 r0 = recLoad(RT_HOT(0, rs)), r1 = recLoad(RT_HOT(1, rs)), e4 = recLoad(RT_COLD(0, rs)), l4 = recLoad(RT_COLD(1, rs));
+                            const int bounce = DIEL ? (__float_as_int(meta.y) & (kPoolInsideBit - 1)) : __float_as_int(meta.y);
                             V3 L = v3(l4.x, l4.y, l4.z) + v3(e4.x, e4.y, e4.z) * shadeMiss(sky, v3(r0.w, r1.x, r1.y));
-                            poolStoreSample(b.sampleL + RT_REC_PATH(rs), L, bounce + 1);
+                            poolStoreSample(b.sampleL + __float_as_uint(e4.w), L, bounce + 1);
                         } else if (inst == kPoolUnsettled) {
                             poolHandOver(a, RT_REC_PIX(rs));
                         }
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                         const uint32_t mine = (uint32_t)__popcll(me & laneBelow);
                         const unsigned long long p = base + mine;
                         if (noMoreWork) { }
-                        else if (p >= pathEnd) { RT_REC_INST(s) = kPoolFresh; fresh = true; }
+                        else if (p >= pathEnd) { RT_REC_STATE(s) = kPoolFresh; fresh = true; }
                         else {
                             const int rs = s;
                             uint32_t wItem = baseItem + mine;
@@ -331,18 +334,17 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                                     const Ray r = cameraRay(a.cb, pixelToNdc(x, jx, a.width), pixelToNdc(y, jy, a.height));
                                     if (rayDegenerate(r)) poolHandOver(a, pix);
                                     else {
-                                        recStore(RT_REC(0, rs), make_float4(r.origin.x, r.origin.y, r.origin.z, r.direction.x));
-                                        recStore(RT_REC(1, rs), make_float4(r.direction.y, r.direction.z, r.invDir.x, r.invDir.y));
-                                        recStore(RT_REC(2, rs), make_float4(r.invDir.z, __uint_as_float(pix), __uint_as_float(key), __int_as_float(0)));
-                                        RT_REC_PATH(rs) = (uint32_t)p;
-                                        recStore(RT_REC(5, rs), make_float4(1.f, 1.f, 1.f, 0.f));
-                                        recStore(RT_REC(6, rs), make_float4(0.f, 0.f, 0.f, 0.f));
+                                        recStore(RT_HOT(0, rs), make_float4(r.origin.x, r.origin.y, r.origin.z, r.direction.x));
+                                        recStore(RT_HOT(1, rs), make_float4(r.direction.y, r.direction.z, r.invDir.x, r.invDir.y));
+                                        recStore(RT_HOT(2, rs), make_float4(r.invDir.z, __int_as_float(0), __uint_as_float(key), __int_as_float(0)));
+                                        recStore(RT_COLD(0, rs), make_float4(1.f, 1.f, 1.f, __uint_as_float((uint32_t)p)));
+                                        recStore(RT_COLD(1, rs), make_float4(0.f, 0.f, 0.f, __uint_as_float(pix)));
                                         live = true;
                                     }
                                 }
                             }
                             if (live) goOn = true;
-                            else { RT_REC_INST(rs) = kPoolFresh; fresh = true; }     // no such path: take another one next time
+                            else { RT_REC_STATE(rs) = kPoolFresh; fresh = true; }     // no such path: take another one next time
                         }
                     }
                 } else if (kind == 1 && ended) fresh = true;          // ended at a surface: queued for a new path
@@ -369,8 +371,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             if (idleLane && mine < k) {
                 slot = rayQ[(rayHead + mine) & (kPoolQueue - 1)];
                 {
-                    const float4 r0 = recLoad(RT_REC(0, slot)), r1 = recLoad(RT_REC(1, slot));
-                    const float iz = RT_REC(2, slot)->x;
+                    const float4 r0 = recLoad(RT_HOT(0, slot)), r1 = recLoad(RT_HOT(1, slot));
+                    const float iz = RT_HOT(2, slot)->x;
                     world.origin = v3(r0.x, r0.y, r0.z);
                     world.direction = v3(r0.w, r1.x, r1.y);
                     world.invDir = v3(r1.z, r1.w, iz);
@@ -405,9 +407,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
 #undef RT_WORLD_RAY
 #undef RT_REDO
 #undef RT_STAT
-#undef RT_REC
-#undef RT_REC_INST
-#undef RT_REC_PATH
+#undef RT_HOT
+#undef RT_COLD
+#undef RT_REC_STATE
 #undef RT_REC_PIX
 #undef RT_REC_BOUNCE
     if (STATS) {
