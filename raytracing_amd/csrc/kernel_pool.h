@@ -34,8 +34,11 @@ struct alignas(32) PoolRec { float4 piece[6]; };
 static_assert(sizeof(PoolRec) == 96, "64 hot + 32 cold bytes per path");
 
 constexpr int32_t kPoolMiss = -1, kPoolUnsettled = -3, kPoolFresh = -4;
-constexpr int kPoolSlots = 128;      // paths per wave (record slots); 144 .. 192 gain 1-2 % on a scene that fits the caches and lose 2-4 % on one that does not
-constexpr int kPoolQueue = 128;      // entries per queue (power of two >= kPoolSlots; a slot index fits a byte)
+#ifndef RT_POOL_SLOTS
+#define RT_POOL_SLOTS 128
+#endif
+constexpr int kPoolSlots = RT_POOL_SLOTS;      // paths per wave (record slots); 144 .. 192 gain 1-2 % on a scene that fits the caches and lose 2-4 % on one that does not
+constexpr int kPoolQueue = RT_POOL_SLOTS > 128 ? 256 : 128;      // entries per queue (power of two >= kPoolSlots; a slot index fits a byte)
 constexpr int kPoolChunk = 256;      // path indices a wave takes from the batch at a time (fewer when the batch is small)
 #ifndef RT_POOL_HOT_NODES
 #define RT_POOL_HOT_NODES 376
