@@ -52,10 +52,10 @@ def build_workload(name, width, height, tree=0):
 
 
 def cpu_baseline(buf, frame, sky, width, height, spp, bounces, seed):
-    """Time the scalar CPU oracle on a bounded sample of the same workload (about 10-20 s)."""
+    """Time the scalar CPU oracle on a bounded sample of the same workload (about 15 s on 16 cores)."""
     from oracle import oracle as O
     cores = min(os.cpu_count() or 1, 16)
-    sspp = max(1, min(8, spp // 8))
+    sspp = max(1, min(32, spp // 8))
     t0 = time.time()
     r = O.render(buf, frame, width, height, sky=sky, mode=1, spp=sspp, max_bounces=bounces, seed=seed, nthreads=cores,
                  want_ids=False, want_t=False)

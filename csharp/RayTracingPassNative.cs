@@ -23,6 +23,9 @@ namespace Script.RayTracing
         }
 
         [DllImport(Lib)] public static extern int rtamd_ctx_create(int device, out IntPtr ctx);
+        // one context over several GPUs of the node (scene replicated, frame tile-sharded, gathered with RCCL inside the library)
+        [DllImport(Lib)] public static extern int rtamd_ctx_create_multi(int* deviceOrdinals, int nDevices, out IntPtr ctx);
+        [DllImport(Lib)] public static extern int rtamd_multi_info(IntPtr ctx, out int nDevices, out int rcclRanks, out float lastExchangeMs);
         [DllImport(Lib)] public static extern int rtamd_ctx_destroy(IntPtr ctx);
         [DllImport(Lib)] public static extern IntPtr rtamd_last_error_string(IntPtr ctx);
         [DllImport(Lib)] public static extern int rtamd_scene_upload(IntPtr ctx,
@@ -67,6 +70,14 @@ namespace Script.RayTracing
         {
             if (RtAmd.rtamd_ctx_create(device, out ctx) != 0)
                 throw new InvalidOperationException(Marshal.PtrToStringAnsi(RtAmd.rtamd_last_error_string(IntPtr.Zero)));
+        }
+
+        // Every listed GPU renders its share of each frame; the frame comes back whole.
+        public NativeRayTracer(int[] devices)
+        {
+            fixed (int* d = devices)
+                if (RtAmd.rtamd_ctx_create_multi(d, devices.Length, out ctx) != 0)
+                    throw new InvalidOperationException(Marshal.PtrToStringAnsi(RtAmd.rtamd_last_error_string(IntPtr.Zero)));
         }
 
         // Body of Execute between the ObjectsCount guard (:68) and the Blit (:105).
