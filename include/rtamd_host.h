@@ -155,12 +155,12 @@ int rtamd_host_scene_load(rtamd_host_scene* s, const char* path);
 /* Reads the lat-long sky the shader samples as _SkyboxTexture
  * (Assets/Shaders/RayTracingShader.compute:22,409; the reference ships
  * the .exr files of Assets/SkyBoxes through Unity's importer) from the file itself:
- * OpenEXR (single-part scanline; NONE / RLE / ZIPS / ZIP; HALF, FLOAT or UINT
+ * OpenEXR (single-part scanline; NONE / RLE / ZIPS / ZIP / PIZ; HALF, FLOAT or UINT
  * R,G,B,A or Y) or Radiance RGBE (.hdr).  Returns RGBA float32, malloc'ed, to be
  * released with rtamd_host_image_free.  flip_y = 1 puts the file's bottom scanline
  * in row 0, which is Unity's texture space (v = 0 at the bottom) and what
  * rtamd_sky_upload expects; 0 keeps file order.  Returns 0, or -1 with
- * rtamd_host_last_error set (PIZ and the lossy codecs are not supported). */
+ * rtamd_host_last_error set (the lossy codecs are not supported). */
 int rtamd_host_image_load(const char* path, int32_t flip_y, float** out_rgba, int32_t* out_w, int32_t* out_h);
 void rtamd_host_image_free(float* rgba);
 /* Writes RGBA float32 by extension: .exr (FLOAT RGBA, ZIP), .hdr (flat RGBE, alpha

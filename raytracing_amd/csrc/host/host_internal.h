@@ -20,6 +20,11 @@ int bvhBuildSah(const rtamd_aabb* aabbs, int n, rtamd_node* nodes, int capacity,
 void setLastError(const std::string& msg);
 const std::string& lastError();
 
+// One PIZ-compressed OpenEXR chunk -> the bytes of the same chunk stored uncompressed (row after row, channel
+// after channel).  chanWords[k]: 16-bit words per pixel of channel k (HALF 1, FLOAT / UINT 2).  (exr_piz.cpp)
+bool exrPizDecode(const uint8_t* src, size_t n, const std::vector<int>& chanWords, int width, int rows,
+                  std::vector<uint8_t>& out, std::string& why);
+
 struct Blas {                         // BottomLevelAccelerateStructure, RayTracableComponent.cs:10-20
     std::vector<rtamd_node> nodes;
     std::vector<float> vertices;      // 3 per vertex

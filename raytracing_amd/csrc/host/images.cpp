@@ -4,7 +4,7 @@
 // Unity-imported lat-long .exr (Assets/SkyBoxes/*.exr.meta; the pixel data is not part of
 // the checkout).  Outside Unity the texture has to be read from the file itself:
 //   * OpenEXR, single-part scanline files, HALF / FLOAT / UINT channels named R,G,B,A (or Y),
-//     compression NONE, RLE, ZIPS, ZIP.  PIZ and the lossy codecs are reported as
+//     compression NONE, RLE, ZIPS, ZIP, PIZ (exr_piz.cpp).  The lossy codecs are reported as
 //     unsupported.
 //   * Radiance RGBE (.hdr / .pic), flat and new-style run-length scanlines, -Y +X order.
 // Image files store the top scanline first; Unity's texture space has v = 0 at the bottom
@@ -146,8 +146,8 @@ bool loadExr(const std::vector<uint8_t>& file, bool flip, std::vector<float>& rg
     switch (compression) {
         case 0: case 1: case 2: linesPerBlock = 1; break;
         case 3: linesPerBlock = 16; break;
-        case 4: setLastError("OpenEXR PIZ compression is not supported (re-save as ZIP or uncompressed)"); return false;
-        default: setLastError("unsupported OpenEXR compression"); return false;
+        case 4: linesPerBlock = 32; break;
+        default: setLastError("unsupported OpenEXR compression (NONE, RLE, ZIPS, ZIP and PIZ are read; re-save lossy files)"); return false;
     }
     size_t lineBytes = 0;
     std::vector<size_t> chOffset;
@@ -193,6 +193,12 @@ bool loadExr(const std::vector<uint8_t>& file, bool flip, std::vector<float>& rg
         if ((size_t)size == expect || compression == 0) {
             if ((size_t)size != expect) { setLastError("bad uncompressed OpenEXR chunk size"); return false; }
             block.assign(src, src + size);
+        } else if (compression == 4) {
+            std::vector<int> words;
+            for (const ExrChannel& k : ch) words.push_back(k.type == 1 ? 1 : 2);
+            std::string why;
+            if (!rtamd_host::exrPizDecode(src, (size_t)size, words, W, rows, block, why)) { setLastError("bad PIZ data in OpenEXR chunk: " + why); return false; }
+            if (block.size() != expect) { setLastError("bad PIZ data in OpenEXR chunk"); return false; }
         } else if (compression == 1) {
             if (!exrRleDecode(src, (size_t)size, block, expect)) { setLastError("bad RLE data in OpenEXR chunk"); return false; }
             exrUnfilter(block, tmp);

@@ -41,7 +41,154 @@ def _exr_rle(data: bytes) -> bytes:
     return bytes(out)
 
 
-def write_exr(path, img, pixel_type, compression, channels="ABGR"):
+def _wavelet_encode(a, mx):
+    """a: (ny, nx) int64 view of one 16-bit word plane, transformed in place (OpenEXR's 2-D wavelet)."""
+    ny, nx = a.shape
+    w14 = mx < (1 << 14)
+
+    def enc(x, y):
+        if w14:
+            xs = np.where(x >= 32768, x - 65536, x)
+            ys = np.where(y >= 32768, y - 65536, y)
+            return ((xs + ys) >> 1) & 0xffff, (xs - ys) & 0xffff
+        ao = (x + 32768) & 0xffff
+        m = (ao + y) >> 1
+        d = ao - y
+        m = np.where(d < 0, (m + 32768) & 0xffff, m)
+        return m, d & 0xffff
+
+    p, p2 = 1, 2
+    while p2 <= min(nx, ny):
+        ys = np.arange(0, ny - p2 + 1, p2)
+        xs = np.arange(0, nx - p2 + 1, p2)
+        Y, X = np.ix_(ys, xs)
+        i00, i01 = enc(a[Y, X], a[Y, X + p])
+        i10, i11 = enc(a[Y + p, X], a[Y + p, X + p])
+        a[Y, X], a[Y + p, X] = enc(i00, i10)
+        a[Y, X + p], a[Y + p, X + p] = enc(i01, i11)
+        if nx & p:
+            xl = len(xs) * p2
+            a[ys, xl], a[ys + p, xl] = enc(a[ys, xl], a[ys + p, xl])
+        if ny & p:
+            yl = len(ys) * p2
+            a[yl, xs], a[yl, xs + p] = enc(a[yl, xs], a[yl, xs + p])
+        p, p2 = p2, p2 << 1
+
+
+def _huffman_lengths(freq):
+    import heapq
+    heap = [(f, s, None, None) for s, f in sorted(freq.items())]
+    heapq.heapify(heap)
+    tick = 1 << 20
+    while len(heap) > 1:
+        a = heapq.heappop(heap)
+        b = heapq.heappop(heap)
+        heapq.heappush(heap, (a[0] + b[0], tick, a, b))
+        tick += 1
+    lengths = {}
+    stack = [(heap[0], 0)]
+    while stack:
+        node, d = stack.pop()
+        if node[2] is None:
+            lengths[node[1]] = max(d, 1)
+        else:
+            stack.append((node[2], d + 1))
+            stack.append((node[3], d + 1))
+    return lengths
+
+
+def _piz_block(planes, flat_code=False):
+    """planes: list of (rows, width, words-per-pixel) uint16 arrays, one per channel in file order.
+    An independent encoder of OpenEXR's PIZ block layout: bitmap of used values, wavelet, Huffman + runs."""
+    words = np.concatenate([p.reshape(-1) for p in planes]).astype(np.int64)
+    used = np.zeros(65536, dtype=bool)
+    used[words] = True
+    bitmap = np.packbits(used, bitorder="little")
+    bitmap[0] &= 0xfe
+    nz = np.nonzero(bitmap)[0]
+    lo, hi = (int(nz[0]), int(nz[-1])) if len(nz) else (8191, 0)
+    used[0] = True
+    lut = np.cumsum(used) - 1
+    mx = int(lut[-1])
+    words = lut[words]
+    at = 0
+    for p in planes:
+        rows, width, size = p.shape
+        v = words[at:at + p.size].reshape(rows, width, size)
+        for j in range(size):
+            plane = v[:, :, j].copy()
+            _wavelet_encode(plane, mx)
+            v[:, :, j] = plane
+        at += p.size
+    out = struct.pack("<HH", lo, hi) + (bitmap[lo:hi + 1].tobytes() if lo <= hi else b"")
+    # Huffman: symbols = values, plus one run symbol just after the largest value
+    vals, counts = np.unique(words, return_counts=True)
+    freq = {int(v): int(c) for v, c in zip(vals, counts)}
+    im, iM = min(freq), max(freq) + 1
+    freq[iM] = 1
+    lengths = _huffman_lengths(freq)
+    if flat_code:                           # every code equally long and longer than the decoder's 14-bit table
+        lengths = {s: 17 for s in lengths}
+    assert max(lengths.values()) <= 58
+    count = [0] * 60
+    for l in lengths.values():
+        count[l] += 1
+    start, c = [0] * 60, 0
+    for l in range(58, 0, -1):
+        start[l] = c
+        c = (c + count[l]) >> 1
+    code = {}
+    for s in sorted(lengths):
+        code[s] = start[lengths[s]]
+        start[lengths[s]] += 1
+    bits = []
+    s = im
+    while s <= iM:
+        l = lengths.get(s, 0)
+        if l == 0:
+            run = 1
+            while s + run <= iM and run < 261 and lengths.get(s + run, 0) == 0:
+                run += 1
+            if run >= 6:
+                bits.append(format(63, "06b") + format(run - 6, "08b"))
+            elif run >= 2:
+                bits.append(format(59 + run - 2, "06b"))
+            else:
+                bits.append(format(0, "06b"))
+            s += run
+        else:
+            bits.append(format(l, "06b"))
+            s += 1
+    table = "".join(bits)
+    table += "0" * (-len(table) % 8)
+    table = int(table, 2).to_bytes(len(table) // 8, "big") if table else b""
+    bits = []
+
+    def send(sym, extra):
+        cs, cr = format(code[sym], "0%db" % lengths[sym]), format(code[iM], "0%db" % lengths[iM])
+        if len(cs) + len(cr) + 8 < len(cs) * extra:
+            bits.append(cs + cr + format(extra, "08b"))
+        else:
+            bits.append(cs * (extra + 1))
+
+    w = words.tolist()
+    cur, extra = w[0], 0
+    for v in w[1:]:
+        if v == cur and extra < 255:
+            extra += 1
+        else:
+            send(cur, extra)
+            cur, extra = v, 0
+    send(cur, extra)
+    data = "".join(bits)
+    n_bits = len(data)
+    data += "0" * (-n_bits % 8)
+    data = int(data, 2).to_bytes(len(data) // 8, "big")
+    huf = struct.pack("<IIIII", im, iM, len(table), n_bits, 0) + table + data
+    return out + struct.pack("<i", len(huf)) + huf
+
+
+def write_exr(path, img, pixel_type, compression, channels="ABGR", piz_flat_code=False):
     """img: (h, w, len(channels)) float32 in file row order (top first), channel order as named."""
     h, w, nc = img.shape
     order = sorted(range(nc), key=lambda i: channels[i])
@@ -60,7 +207,7 @@ def write_exr(path, img, pixel_type, compression, channels="ABGR"):
     hdr += attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0))
     hdr += attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
     hdr += b"\0"
-    lines = 16 if compression == 3 else 1
+    lines = {3: 16, 4: 32}.get(compression, 1)
     chunks = []
     for y0 in range(0, h, lines):
         raw = bytearray()
@@ -71,6 +218,14 @@ def write_exr(path, img, pixel_type, compression, channels="ABGR"):
         raw = bytes(raw)
         if compression == 0:
             data = raw
+        elif compression == 4:
+            y1 = min(h, y0 + lines)
+            planes = []
+            for i in order:
+                col = np.ascontiguousarray(img[y0:y1, :, i])
+                col = col.astype(np.float16) if pixel_type == 1 else col.astype(np.float32)
+                planes.append(col.view(np.uint16).reshape(y1 - y0, w, -1))
+            data = _piz_block(planes, piz_flat_code)
         elif compression == 1:
             data = _exr_rle(_exr_filter(raw))
         else:
@@ -110,6 +265,61 @@ def test_exr_read(tmp_path, compression, pixel_type):
     assert np.array_equal(H.load_image(p, flip_y=True), want[::-1])
 
 
+@pytest.mark.parametrize("case", ["half_small", "float_small", "half_smooth", "float_many_values", "flat", "long_codes"])
+def test_exr_piz_read(tmp_path, case):
+    """PIZ blocks written by this file's encoder: the 14-bit and the 16-bit wavelet (fewer / more than 16384
+    distinct 16-bit values in a block), odd sizes at every wavelet level, a partial last block, runs, an
+    all-zero block, Huffman codes longer than the decoder's 14-bit table."""
+    if case == "half_small":
+        img, pt = _picture(37, 23, 21), 1
+    elif case == "float_small":
+        img, pt = _picture(37, 23, 22), 2
+    elif case == "half_smooth":
+        y, x = np.mgrid[0:70, 0:129].astype(np.float32)
+        img = np.stack([np.sin(x / 17) + 2, np.cos(y / 9) * 3 + 4, (x + y) / 50, np.ones_like(x)], axis=-1).astype(np.float32)
+        img[10:60, 5:100, 2] = 0.5
+        pt = 1
+    elif case == "float_many_values":
+        img, pt = _picture(40, 300, 23), 2
+    elif case == "flat":
+        img, pt = np.zeros((33, 10, 4), dtype=np.float32), 1
+        img[32] = 1.5
+    else:
+        img, pt = _picture(19, 31, 24), 1
+    p = tmp_path / "piz.exr"
+    write_exr(p, img[..., [3, 2, 1, 0]], pt, 4, piz_flat_code=(case == "long_codes"))
+    want = img.astype(np.float16).astype(np.float32) if pt == 1 else img
+    got = H.load_image(p, flip_y=False)
+    assert got.shape == img.shape
+    assert np.array_equal(got, want)
+
+
+def test_exr_piz_corrupt_blocks_are_errors(tmp_path):
+    img = _picture(37, 23, 25)
+    good = tmp_path / "good.exr"
+    write_exr(good, img[..., [3, 2, 1, 0]], 1, 4)
+    data = good.read_bytes()
+    H.load_image(good)
+    rng = np.random.default_rng(3)
+    refused = 0
+    for trial in range(200):
+        d = bytearray(data)
+        at = int(rng.integers(len(d) - 2000, len(d)))
+        d[at] ^= 1 << int(rng.integers(8))
+        p = tmp_path / "bad.exr"
+        p.write_bytes(bytes(d))
+        try:
+            got = H.load_image(p, flip_y=False)       # a flipped data bit may still decode: to other values, same shape
+            assert got.shape == img.shape
+        except H.HostError:
+            refused += 1
+    assert refused > 0
+    p = tmp_path / "cut.exr"
+    p.write_bytes(data[:-100])
+    with pytest.raises(H.HostError):
+        H.load_image(p)
+
+
 def test_exr_rgb_without_alpha_and_luminance_only(tmp_path):
     img = _picture(9, 12, 5)
     p = tmp_path / "rgb.exr"
@@ -125,9 +335,9 @@ def test_exr_rgb_without_alpha_and_luminance_only(tmp_path):
 
 def test_exr_unsupported_and_corrupt_files_are_errors(tmp_path):
     img = _picture(4, 4, 1)
-    p = tmp_path / "piz.exr"
-    write_exr(p, img[..., [3, 2, 1, 0]], 2, 4)          # PIZ id in the header
-    with pytest.raises(H.HostError, match="PIZ"):
+    p = tmp_path / "b44.exr"
+    write_exr(p, img[..., [3, 2, 1, 0]], 2, 6)          # B44 (lossy) id in the header
+    with pytest.raises(H.HostError, match="unsupported"):
         H.load_image(p)
     p = tmp_path / "cut.exr"
     write_exr(p, img[..., [3, 2, 1, 0]], 2, 0)
