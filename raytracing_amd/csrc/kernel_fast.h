@@ -453,6 +453,7 @@ template <int MODE, bool STATS, bool DIEL = false>
 __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene sc, Sky sky, RenderArgs a, int refillBelow, int nodeMin, int leafGroupMin,
                                                        int stackLimit, unsigned long long* stats) {
     unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define RT_STAT2(slot, cond) do { } while (0)
 #define RT_STAT(slot, cond)                                                         \
     do {                                                                            \
         if (STATS) {                                                                \
@@ -654,6 +655,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
 #undef RT_WORLD_RAY
 #undef RT_REDO
 #undef RT_STAT
+#undef RT_STAT2
     if (STATS) {
         for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(deepest, off, 64); deepest = o > deepest ? o : deepest; }
         if (lane == 0) {

@@ -94,7 +94,7 @@ __device__ __forceinline__ void poolHandOver(const RenderArgs& a, uint32_t p) {
 }
 
 // STATS = true builds a diagnostic variant that also counts, per phase, how often the wave executed
-// it and with how many active lanes (written to `stats`, 24 counters; see launchPool for the names).
+// it and with how many active lanes (written to `stats`, 25 counters; see launchPool for the names).
 // DIEL = true (RTAMD_FLAG_DIELECTRICS): glass objects refract; bit 16 of a record's bounce word says that
 // the path is inside glass, and such a ray tests triangles from both sides.
 constexpr int32_t kPoolInsideBit = 1 << 16;
@@ -102,7 +102,7 @@ template <bool STATS, bool DIEL = false>
 __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene sc, Sky sky, RenderArgs a, PoolBatch b, int refillBelow,
                                                                        int nodeMin, int leafGroupMin, int stackLimit, int poolSlots,
                                                                        unsigned long long* stats) {
-    unsigned long long st_[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // 12 phases x (executions, lanes)
 #define RT_STAT(slot, cond)                                                         \
     do {                                                                            \
         if (STATS) {                                                                \
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             if (m_) { st_[2 * (slot)] += 1; st_[2 * (slot) + 1] += __popcll(m_); }  \
         }                                                                           \
     } while (0)
+#define RT_STAT2(slot, cond) RT_STAT(slot, cond)
     __shared__ int32_t ldsStack[kLdsStack][kBlockThreads];
     __shared__ float4 ldsNodes[kPoolHotNodes * kHotStride];
     __shared__ uint8_t ldsQueues[kBlockThreads / 64][3][kPoolQueue];
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
 #undef RT_WORLD_RAY
 #undef RT_REDO
 #undef RT_STAT
+#undef RT_STAT2
 #undef RT_HOT
 #undef RT_COLD
 #undef RT_REC_STATE
@@ -418,8 +420,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
     if (STATS) {
         for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(deepest, off, 64); deepest = o > deepest ? o : deepest; }
         if (lane == 0) {
-            for (int i = 0; i < 23; i++) if (st_[i]) atomicAdd(stats + i, st_[i]);
-            atomicMax(stats + 23, (unsigned long long)deepest);
+            for (int i = 0; i < 24; i++) if (st_[i]) atomicAdd(stats + i, st_[i]);
+            atomicMax(stats + 24, (unsigned long long)deepest);
         }
     }
 }
@@ -582,8 +584,8 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     }
 
     if (cfg.stats) {
-        if ((e = fs.stats.ensure(24)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(fs.stats.p, 0, 24 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+        if ((e = fs.stats.ensure(25)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(fs.stats.p, 0, 25 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
     }
     for (size_t t0 = 0; t0 < fs.hSuper.size(); t0 += tilesPerChunk) {
         const size_t nt = fs.hSuper.size() - t0 < tilesPerChunk ? fs.hSuper.size() - t0 : tilesPerChunk;
@@ -619,13 +621,14 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     }
     if (cfg.stats) {
         // diagnostic build: per-phase execution counts and active lanes of the whole render, to stderr
-        unsigned long long h[24];
+        unsigned long long h[25];
         if ((e = hipMemcpyAsync(h, fs.stats.p, sizeof(h), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-        const char* names[9] = {"hitPass", "nodeStep", "instEnter", "triLeaf(slot boxes)", "triTest", "publish", "leafPhase(trav lanes)", "nodeLoop(trav lanes)", "endStartPass"};
-        for (int i = 0; i < 9; i++)
+        const char* names[12] = {"hitPass", "nodeStep", "instEnter", "triLeaf(slot boxes)", "triTest", "publish", "leafPhase(trav lanes)", "nodeLoop(trav lanes)", "endStartPass",
+                                 "nodeStep, stale", "instEnter, stale", "nodeStep, no child"};
+        for (int i = 0; i < 12; i++)
             if (h[2 * i]) fprintf(stderr, "[rtamd stats] kPool %-22s executions %12llu  mean active lanes %6.2f\n", names[i], h[2 * i], (double)h[2 * i + 1] / (double)h[2 * i]);
-        fprintf(stderr, "[rtamd stats] kPool deepest traversal stack %llu of %d entries in LDS\n", h[23], kLdsStack);
+        fprintf(stderr, "[rtamd stats] kPool deepest traversal stack %llu of %d entries in LDS\n", h[24], kLdsStack);
     }
     return hipSuccess;
 }

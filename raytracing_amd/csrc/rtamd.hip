@@ -63,7 +63,9 @@ constexpr size_t kNaOffCounters = 0;                // rt::DevCounters (64 B)
 constexpr size_t kNaOffRayCount = 64;               // ray counter, work-queue head (2 x 8 B)
 constexpr size_t kNaOffErrorFlag = 80;
 constexpr size_t kNaOffRedoCount = 84;
-constexpr size_t kNaOffRedoMask = 256;              // one bit per pixel
+constexpr size_t kCtrlBytes = 256;                  // the block of small words in front (what a render clears and reads back)
+constexpr size_t kCtrlUsed = 88;
+constexpr size_t kNaOffRedoMask = kCtrlBytes;       // one bit per pixel
 constexpr size_t kNaOffRedoList = kNaOffRedoMask + (size_t)(kNaMaxPixels / 32) * 4;
 constexpr size_t kNaOffSuperTiles = kNaOffRedoList + (size_t)kNaRedoCap * 4;
 constexpr size_t kNaOffSamples = kNaOffSuperTiles + (size_t)kNaMaxTiles * 4;
@@ -130,12 +132,14 @@ struct rtamd_ctx {
     DevBuf<float4> outRgba;      // staging when the caller passes host pointers
     DevBuf<int32_t> outIds;
     DevBuf<float> outT;
-    DevBuf<rt::DevCounters> counters;     // [0] counters
-    DevBuf<unsigned long long> rayCount;  // [0] rays, [1] work-queue head
-    DevBuf<int32_t> errorFlag;
+    // The small words every render clears and reads back — counters, ray count + work-queue head, error flag,
+    // hand-over count — sit in one 256-byte block (laid out like the head of `scratch`), so a render clears
+    // them with one fill and reads them with one copy into pinned host memory.
+    DevBuf<unsigned char> ctrl;
+    unsigned char* hostCtrl = nullptr;    // pinned, kCtrlBytes
 
     DevBuf<uint32_t> redoMask;            // pixels handed from the production kernel to the reference-order kernel
-    DevBuf<int32_t> redoList, redoCount;
+    DevBuf<int32_t> redoList;
     DevBuf<float4> redoSamples;
     int32_t lastRedoPixels = 0;
     float lastKernelMs = 0.f, lastHandoverMs = 0.f, lastTraceMs = 0.f;
@@ -262,7 +266,7 @@ int rtamd_ctx_create(int device_ordinal, rtamd_ctx** out_ctx) {
     c->device = device_ordinal;
     if ((e = hipSetDevice(device_ordinal)) != hipSuccess || (e = scratchForDevice(device_ordinal, &c->naScratch)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess ||
-        (e = c->counters.alloc(1)) != hipSuccess || (e = c->rayCount.alloc(2)) != hipSuccess || (e = c->errorFlag.alloc(1)) != hipSuccess || (e = c->redoCount.alloc(1)) != hipSuccess) {
+        (e = c->ctrl.alloc(kCtrlBytes)) != hipSuccess || (e = hipHostMalloc((void**)&c->hostCtrl, kCtrlBytes, hipHostMallocDefault)) != hipSuccess) {
         int rc = failHip(nullptr, e, "context creation");
         rtamd_ctx_destroy(c);
         return rc;
@@ -292,8 +296,9 @@ int rtamd_ctx_destroy(rtamd_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->tlas.release(); c->blas.release(); c->blasOffsets.release(); c->vtxOffsets.release(); c->triOffsets.release();
     c->verts.release(); c->tris.release(); c->objects.release(); c->sky.release(); c->accum.release();
-    c->tmp8.release(); c->outRgba.release(); c->outIds.release(); c->outT.release(); c->counters.release(); c->rayCount.release();
-    c->errorFlag.release(); c->redoMask.release(); c->redoList.release(); c->redoCount.release(); c->redoSamples.release();
+    c->tmp8.release(); c->outRgba.release(); c->outIds.release(); c->outT.release(); c->ctrl.release();
+    c->redoMask.release(); c->redoList.release(); c->redoSamples.release();
+    if (c->hostCtrl) (void)hipHostFree(c->hostCtrl);
     c->fast.release();
     c->pool.release();
     if (c->evStart) (void)hipEventDestroy(c->evStart);
@@ -489,10 +494,11 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
     }
     // working memory of this call
     unsigned char* const na = c->naScratch;
-    rt::DevCounters* const dCounters = noAlloc ? (rt::DevCounters*)(na + kNaOffCounters) : c->counters.p;
-    unsigned long long* const dRayCount = noAlloc ? (unsigned long long*)(na + kNaOffRayCount) : c->rayCount.p;
-    int32_t* const dErrorFlag = noAlloc ? (int32_t*)(na + kNaOffErrorFlag) : c->errorFlag.p;
-    int32_t* const dRedoCount = noAlloc ? (int32_t*)(na + kNaOffRedoCount) : c->redoCount.p;
+    unsigned char* const ctrl = noAlloc ? na : c->ctrl.p;
+    rt::DevCounters* const dCounters = (rt::DevCounters*)(ctrl + kNaOffCounters);
+    unsigned long long* const dRayCount = (unsigned long long*)(ctrl + kNaOffRayCount);
+    int32_t* const dErrorFlag = (int32_t*)(ctrl + kNaOffErrorFlag);
+    int32_t* const dRedoCount = (int32_t*)(ctrl + kNaOffRedoCount);
     const rt::LaunchScratch lent = {(int32_t*)(na + kNaOffSuperTiles), kNaMaxTiles};
 
     rt::RenderArgs a;
@@ -550,9 +556,7 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
     sky.texels = c->sky.p; sky.w = c->skyW; sky.h = c->skyH;
     sky.invW = c->skyW > 0 ? 1.0f / (float)c->skyW : 0.f; sky.invH = c->skyH > 0 ? 1.0f / (float)c->skyH : 0.f;
 
-    rt::DevCounters hc;
-    unsigned long long hr[2] = {0, 0};
-    int32_t herr = 0, redo = 0;
+    int32_t redo = 0;
     float ms = 0.f, handoverMs = 0.f;
     bool usedPool = false;
     const size_t maskWords = (npix + 31) / 32;
@@ -566,11 +570,11 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
         a.redoMask = c->redoMask.p; a.redoList = c->redoList.p; a.redoCap = (int32_t)npix;
     }
     a.redoCount = dRedoCount;
-    HIP_TRY(c, hipMemsetAsync(a.redoMask, 0, maskWords * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(dRedoCount, 0, sizeof(int32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(dCounters, 0, sizeof(rt::DevCounters), c->stream));
-    HIP_TRY(c, hipMemsetAsync(dRayCount, 0, 2 * sizeof(unsigned long long), c->stream));
-    HIP_TRY(c, hipMemsetAsync(dErrorFlag, 0, sizeof(int32_t), c->stream));
+    if (noAlloc) HIP_TRY(c, hipMemsetAsync(ctrl, 0, kCtrlBytes + maskWords * sizeof(uint32_t), c->stream));      // (the mask follows the block)
+    else {
+        HIP_TRY(c, hipMemsetAsync(a.redoMask, 0, maskWords * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(ctrl, 0, kCtrlBytes, c->stream));
+    }
     rt::RefScene rsc;
     rsc.tlas = c->tlas.p; rsc.blasOffsets = c->blasOffsets.p; rsc.blas = c->blas.p; rsc.vtxOffsets = c->vtxOffsets.p;
     rsc.verts = c->verts.p; rsc.triOffsets = c->triOffsets.p; rsc.tris = c->tris.p; rsc.objects = c->objects.p;
@@ -590,8 +594,19 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
         HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&redo, dRedoCount, sizeof(redo), hipMemcpyDeviceToHost, c->stream));
+    // one read-back of the block; with nothing handed over it is final, and the caller's host buffers (if any)
+    // can be filled behind it before the one synchronisation of the call
+    const bool hostOutputs = (out_rgba && !rgbaDev) || (out_prim_id && !idsDev) || (e.out_t && !tDev);
+    auto copyOutputs = [&]() -> hipError_t {
+        hipError_t ce = hipSuccess;
+        if (out_rgba && !rgbaDev) ce = hipMemcpyAsync(out_rgba, c->outRgba.p, npix * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
+        if (ce == hipSuccess && out_prim_id && !idsDev) ce = hipMemcpyAsync(out_prim_id, c->outIds.p, npix * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+        if (ce == hipSuccess && e.out_t && !tDev) ce = hipMemcpyAsync(e.out_t, c->outT.p, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        return ce;
+    };
+    HIP_TRY(c, hipMemcpyAsync(c->hostCtrl, ctrl, kCtrlUsed, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::memcpy(&redo, c->hostCtrl + kNaOffRedoCount, sizeof(redo));
     HIP_TRY(c, hipEventElapsedTime(&ms, c->evStart, c->evStop));
     c->lastTraceMs = usedPool ? c->pool.tracedMs() : ms;
     if (redo > 0) {
@@ -627,23 +642,27 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
         }
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->hostCtrl, ctrl, kCtrlUsed, hipMemcpyDeviceToHost, c->stream));      // counters and flags now include the pass
+        if (hostOutputs) HIP_TRY(c, copyOutputs());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipEventElapsedTime(&ms2, c->evStart, c->evStop));
         ms += ms2;
         handoverMs = ms2;
+    } else if (hostOutputs) {
+        HIP_TRY(c, copyOutputs());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    rt::DevCounters hc;
+    unsigned long long hr[2];
+    int32_t herr;
+    std::memcpy(&hc, c->hostCtrl + kNaOffCounters, sizeof(hc));
+    std::memcpy(hr, c->hostCtrl + kNaOffRayCount, sizeof(hr));
+    std::memcpy(&herr, c->hostCtrl + kNaOffErrorFlag, sizeof(herr));
     c->lastRedoPixels = redo;
     c->lastHandoverMs = handoverMs;
     if (getenv("RTAMD_VERBOSE"))
         fprintf(stderr, "[rtamd] render %dx%d mode %d: %.3f ms, %d pixels handed to the reference-order kernel; nodes %zu (BLAS %zu), depth BLAS %d TLAS %d, instances %d\n",
                 width, height, a.mode, ms, redo, c->fast.hNodes.size(), c->fast.nBlasNodes, c->fast.maxDepth, c->fast.tlasDepth, c->fast.nInst);
-    HIP_TRY(c, hipMemcpyAsync(&hc, dCounters, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(hr, dRayCount, sizeof(hr), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&herr, dErrorFlag, sizeof(herr), hipMemcpyDeviceToHost, c->stream));
-    if (out_rgba && !rgbaDev) HIP_TRY(c, hipMemcpyAsync(out_rgba, c->outRgba.p, npix * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
-    if (out_prim_id && !idsDev) HIP_TRY(c, hipMemcpyAsync(out_prim_id, c->outIds.p, npix * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (e.out_t && !tDev) HIP_TRY(c, hipMemcpyAsync(e.out_t, c->outT.p, npix * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->lastKernelMs = ms;
     c->lastRays = hr[0];
     if (wantCounters) {
