@@ -181,6 +181,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                 const int rs = slot;
                 if (toHit) {
                     recStore(RT_HOT(3, rs), make_float4(best.t, best.u, best.v, __int_as_float(best.tri)));
+#ifdef RT_EXP_EXTRA_WRITES
+                    for (int k_ = 0; k_ < RT_EXP_EXTRA_WRITES; k_++) { asm volatile("" ::: "memory"); recStore(RT_HOT(3, rs), make_float4(best.t, best.u, best.v, __int_as_float(best.tri))); }
+#endif
                     RT_REC_STATE(rs) = best.inst;
                     hitQ[(hitTail + __popcll(mh & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)slot;
                 } else {

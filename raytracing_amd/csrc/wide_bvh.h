@@ -22,6 +22,7 @@
 #include <atomic>
 #include <new>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -58,6 +59,7 @@ struct Builder {
     Item* items;
     WideTree* out;
     int maxLeaf;
+    int sweepMax = 0;                // ranges up to this many items are split by an exact sweep instead of bins
     std::atomic<int>* threads;       // builder threads running, shared by the whole build
     std::atomic<bool>* failed;       // a builder thread ran out of memory: the caller throws std::bad_alloc after all have joined
 
@@ -69,9 +71,38 @@ struct Builder {
         }
     }
 
+    // Exact SAH over a small range: the items sorted along each axis, every position tried.
+    int splitSweep(int lo, int hi) {
+        const int n = hi - lo;
+        float bestCost = __builtin_inff();
+        int bestAxis = -1, bestAt = -1;
+        std::vector<float> rArea((size_t)n + 1);
+        for (int axis = 0; axis < 3; axis++) {
+            std::stable_sort(items + lo, items + hi, [axis](const Item& a, const Item& b) { return a.c[axis] < b.c[axis]; });
+            float alo[3], ahi[3];
+            for (int k = 0; k < 3; k++) { alo[k] = __builtin_inff(); ahi[k] = -__builtin_inff(); }
+            for (int i = n - 1; i > 0; i--) {
+                const BuildBox& bx = boxes[items[lo + i].index];
+                for (int k = 0; k < 3; k++) { alo[k] = std::min(alo[k], bx.lo[k]); ahi[k] = std::max(ahi[k], bx.hi[k]); }
+                rArea[(size_t)i] = halfArea(alo, ahi);
+            }
+            for (int k = 0; k < 3; k++) { alo[k] = __builtin_inff(); ahi[k] = -__builtin_inff(); }
+            for (int i = 1; i < n; i++) {
+                const BuildBox& bx = boxes[items[lo + i - 1].index];
+                for (int k = 0; k < 3; k++) { alo[k] = std::min(alo[k], bx.lo[k]); ahi[k] = std::max(ahi[k], bx.hi[k]); }
+                const float cost = halfArea(alo, ahi) * (float)((i + maxLeaf - 1) / maxLeaf) + rArea[(size_t)i] * (float)((n - i + maxLeaf - 1) / maxLeaf);
+                if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestAt = i; }
+            }
+        }
+        if (bestAxis < 0) return lo + n / 2;
+        if (bestAxis != 2) std::stable_sort(items + lo, items + hi, [bestAxis](const Item& a, const Item& b) { return a.c[bestAxis] < b.c[bestAxis]; });
+        return lo + bestAt;
+    }
+
     // split [lo,hi) in two; returns mid with lo < mid < hi
     int split(int lo, int hi) {
         const int n = hi - lo;
+        if (n <= sweepMax) return splitSweep(lo, hi);
         float clo[3], chi[3];
         for (int k = 0; k < 3; k++) { clo[k] = __builtin_inff(); chi[k] = -__builtin_inff(); }
         for (int i = lo; i < hi; i++)
@@ -245,6 +276,7 @@ inline void buildWideTree(const BuildBox* boxes, int n, int maxLeaf, WideTree& o
     b.items = items.data();
     b.out = &out;
     b.maxLeaf = maxLeaf;
+    if (const char* sv = getenv("RTAMD_EXP_SWEEP")) b.sweepMax = atoi(sv);
     b.threads = &threads;
     for (int i = 0; i < n; i++) {
         for (int k = 0; k < 3; k++) items[i].c[k] = (boxes[i].lo[k] + boxes[i].hi[k]) * 0.5f;
