@@ -531,8 +531,8 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         // measured optima of the three benchmark scenes: shading is cheap here (full waves), so
         // lanes are refilled earlier than in kFast; small scenes (same criterion as kFast's) walk on with few lanes
         const bool allHot = fs.nBlasNodes + (size_t)fs.nTlasNodes <= (size_t)kHotNodes;
-        if (cfg.refillBelow == 0) cfg.refillBelow = 48;
-        if (cfg.nodeMin == 0) cfg.nodeMin = allHot ? 8 : 16;
+        if (cfg.refillBelow == 0) cfg.refillBelow = 40;
+        if (cfg.nodeMin == 0) cfg.nodeMin = allHot ? 12 : 16;
     }
 
     FastScene sc;

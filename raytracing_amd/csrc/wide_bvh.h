@@ -12,8 +12,8 @@
 // can occur are handed to the reference-order kernel).
 //
 // Builder: top-down binned SAH (32 bins, three axes) on box centroids; a node takes the
-// range, splits it, then keeps splitting the part with the largest area * count until it
-// has four parts (or every part fits a leaf).  Large subtrees are built by threads of their own
+// range, splits it, then keeps splitting the part with the largest box until it has four parts
+// (or every part fits a leaf; area * count as the criterion measured 1-2 % slower to trace).  Large subtrees are built by threads of their own
 // (disjoint item ranges, a private node array spliced into the parent's afterwards); the tree does
 // not depend on how many threads ran.
 #pragma once
@@ -60,6 +60,7 @@ struct Builder {
     WideTree* out;
     int maxLeaf;
     int sweepMax = 0;                // ranges up to this many items are split by an exact sweep instead of bins
+    int expPick = 1, expCost = 0;    // which part a node splits next: 1 the largest box (default), 0 area x count, 2 count; cost per item instead of per leaf
     std::atomic<int>* threads;       // builder threads running, shared by the whole build
     std::atomic<bool>* failed;       // a builder thread ran out of memory: the caller throws std::bad_alloc after all have joined
 
@@ -143,8 +144,9 @@ struct Builder {
                 c += cnt[b];
                 if (c == 0 || rCnt[b + 1] == 0) continue;
                 // cost in leaf-sized groups: a leaf holds up to maxLeaf primitives
-                float cost = halfArea(alo, ahi) * (float)((c + maxLeaf - 1) / maxLeaf) +
-                             rArea[b + 1] * (float)((rCnt[b + 1] + maxLeaf - 1) / maxLeaf);
+                float cost = expCost ? halfArea(alo, ahi) * (float)c + rArea[b + 1] * (float)rCnt[b + 1]
+                                     : halfArea(alo, ahi) * (float)((c + maxLeaf - 1) / maxLeaf) +
+                                       rArea[b + 1] * (float)((rCnt[b + 1] + maxLeaf - 1) / maxLeaf);
                 if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
             }
         }
@@ -176,7 +178,7 @@ struct Builder {
                 if (n <= maxLeaf) continue;
                 float blo[3], bhi[3];
                 bounds(segs[s].lo, segs[s].hi, blo, bhi);
-                float score = halfArea(blo, bhi) * (float)n;
+                float score = expPick == 1 ? halfArea(blo, bhi) : (expPick == 2 ? (float)n : halfArea(blo, bhi) * (float)n);
                 if (score > best) { best = score; pick = s; }
             }
             if (pick < 0) break;
@@ -277,6 +279,8 @@ inline void buildWideTree(const BuildBox* boxes, int n, int maxLeaf, WideTree& o
     b.out = &out;
     b.maxLeaf = maxLeaf;
     if (const char* sv = getenv("RTAMD_EXP_SWEEP")) b.sweepMax = atoi(sv);
+    if (const char* sv = getenv("RTAMD_EXP_PICK")) b.expPick = atoi(sv);
+    if (const char* sv = getenv("RTAMD_EXP_COST")) b.expCost = atoi(sv);
     b.threads = &threads;
     for (int i = 0; i < n; i++) {
         for (int k = 0; k < 3; k++) items[i].c[k] = (boxes[i].lo[k] + boxes[i].hi[k]) * 0.5f;
