@@ -355,15 +355,22 @@ constexpr int kBlockThreads = RT_BLOCK_THREADS;  // one workgroup per CU: its 16
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for (<= 128 VGPRs)
 #endif
-constexpr int kLdsStack = 24;        // stack entries per lane, all in LDS: [entry][thread], conflict-free (96 KiB)
-#ifndef RT_HOT_NODES
-#define RT_HOT_NODES 448
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 16
 #endif
-constexpr int kHotNodes = RT_HOT_NODES;       // nodes every workgroup keeps in LDS (63 KiB): the TLAS and the top of the BLAS trees
-constexpr int kHotStride = 9;        // float4 per node in LDS: 144 bytes, so that piece j of 16 different nodes falls on 16 different bank groups
+constexpr int kLdsStack = RT_LDS_STACK;        // stack entries per lane in LDS: [entry][thread], conflict-free (64 KiB); deeper stacks overflow into HBM
+                                               // (the benchmark scenes reach 16 / 22 / 27 entries; a limit of 16 measured no slower than 24)
+#ifndef RT_HOT_NODES
+#define RT_HOT_NODES 864
+#endif
+constexpr int kHotNodes = RT_HOT_NODES;       // nodes every workgroup keeps in LDS (94.5 KiB): the TLAS and the top of the BLAS trees
+#ifndef RT_HOT_STRIDE
+#define RT_HOT_STRIDE 7
+#endif
+constexpr int kHotStride = RT_HOT_STRIDE;        // float4 per node in LDS: 112 bytes = 28 banks, so piece j of 16 consecutive nodes falls on 16 different bank groups
 constexpr int kModeRef = 0, kModePt = 1, kModePrimary = 2;
 constexpr int kNoInstance = -(1 << 24);
-constexpr int kSpillChunk = 12;      // entries moved between the LDS stack and its overflow area in HBM at a time
+constexpr int kSpillChunk = kLdsStack / 2;      // entries moved between the LDS stack and its overflow area in HBM at a time
 constexpr int kSpillMax = 96;        // overflow entries per lane
 
 typedef float f2 __attribute__((ext_vector_type(2)));

@@ -20,16 +20,19 @@
 
 namespace rt {
 
-// A path's record: a 64-byte hot part (what traversal, publishing and refilling touch) and a 32-byte cold part.
+// A path's record: a 64-byte hot part (what traversal and refilling touch) and a 32-byte cold part.
 // Per wave the hot parts of its kPoolSlots slots come first, then the cold parts, so two hot records share a
 // 128-byte line and the record stream through L2 and the fabric is 96 instead of 128 bytes per path.
 //   hot 0   origin.xyz, direction.x
 //   hot 1   direction.yz, invDir.xy
-//   hot 2   invDir.z, bounce (bit 16: inside glass), RNG key, state
-//           state: instance rank of the hit; kPoolMiss; kPoolUnsettled: hand the pixel over; kPoolFresh: no path
-//   hot 3   t, u, v, triangle rank (bits)
+//   hot 2   invDir.z, bounce (bit 16: inside glass), RNG key, -
+//   hot 3   -
 //   cold 0  throughput.xyz, index of the path in the batch's sample buffer
 //   cold 1  radiance gathered so far .xyz (read and written only where a surface emits or the path ends), pixel
+// What a finished ray hands to the shading pass does not go through memory: t, u, v, triangle rank and the
+// record's state (instance rank of the hit; kPoolMiss; kPoolUnsettled: hand the pixel over; kPoolFresh: no path)
+// stay in LDS next to the queues (20 bytes per slot).  Two write requests per ray segment less at L2, each
+// measured to cost 1.5 % on the 1M-triangle scene.
 struct alignas(32) PoolRec { float4 piece[6]; };
 static_assert(sizeof(PoolRec) == 96, "64 hot + 32 cold bytes per path");
 
@@ -41,9 +44,9 @@ constexpr int kPoolSlots = RT_POOL_SLOTS;      // paths per wave (record slots);
 constexpr int kPoolQueue = RT_POOL_SLOTS > 128 ? 256 : 128;      // entries per queue (power of two >= kPoolSlots; a slot index fits a byte)
 constexpr int kPoolChunk = 256;      // path indices a wave takes from the batch at a time (fewer when the batch is small)
 #ifndef RT_POOL_HOT_NODES
-#define RT_POOL_HOT_NODES 376
+#define RT_POOL_HOT_NODES 456
 #endif
-constexpr int kPoolHotNodes = RT_POOL_HOT_NODES;   // LDS: 96 KiB stacks + 6 KiB queues + 53 KiB nodes
+constexpr int kPoolHotNodes = RT_POOL_HOT_NODES;   // LDS: 64 KiB stacks + 6 KiB queues + 40 KiB hit results and states + 50 KiB nodes
 
 struct PoolBatch {
     PoolRec* recs;                // [waves of the grid][kPoolSlots]
@@ -114,6 +117,10 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
     __shared__ int32_t ldsStack[kLdsStack][kBlockThreads];
     __shared__ float4 ldsNodes[kPoolHotNodes * kHotStride];
     __shared__ uint8_t ldsQueues[kBlockThreads / 64][3][kPoolQueue];
+    // what a finished ray leaves for the shading pass stays in LDS (written by one lane of the wave, read by another):
+    // t, u, v, triangle of the hit, and the record's state
+    __shared__ float4 ldsHit[kBlockThreads / 64][kPoolSlots];
+    __shared__ int32_t ldsState[kBlockThreads / 64][kPoolSlots];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
     float4* const recCold = recHot + kPoolSlots * 4;
 #define RT_HOT(piece, sl) (recHot + (sl) * 4 + (piece))
 #define RT_COLD(piece, sl) (recCold + (sl) * 2 + (piece))
-#define RT_REC_STATE(sl) (reinterpret_cast<int32_t*>(RT_HOT(2, sl))[3])
+#define RT_REC_STATE(sl) (ldsState[wave][sl])
 #define RT_REC_BOUNCE(sl) (reinterpret_cast<int32_t*>(RT_HOT(2, sl))[1])
 #define RT_REC_PIX(sl) (reinterpret_cast<uint32_t*>(RT_COLD(1, sl))[3])
     const unsigned long long totalPaths = (unsigned long long)b.nWork * (unsigned long long)b.nSamples;
@@ -180,10 +187,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             if (fin) {
                 const int rs = slot;
                 if (toHit) {
-                    recStore(RT_HOT(3, rs), make_float4(best.t, best.u, best.v, __int_as_float(best.tri)));
-#ifdef RT_EXP_EXTRA_WRITES
-                    for (int k_ = 0; k_ < RT_EXP_EXTRA_WRITES; k_++) { asm volatile("" ::: "memory"); recStore(RT_HOT(3, rs), make_float4(best.t, best.u, best.v, __int_as_float(best.tri))); }
-#endif
+                    ldsHit[wave][rs] = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
                     RT_REC_STATE(rs) = best.inst;
                     hitQ[(hitTail + __popcll(mh & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)slot;
                 } else {
@@ -222,8 +226,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                 if (s >= 0) {
                     const int rs = s;
                     const float4 meta = recLoad(RT_HOT(2, rs));
-                    const float4 r0 = recLoad(RT_HOT(0, rs)), r1 = recLoad(RT_HOT(1, rs)), h4 = recLoad(RT_HOT(3, rs)), e4 = recLoad(RT_COLD(0, rs));
-                    const int32_t inst = __float_as_int(meta.w);
+                    const float4 r0 = recLoad(RT_HOT(0, rs)), r1 = recLoad(RT_HOT(1, rs)), h4 = ldsHit[wave][rs], e4 = recLoad(RT_COLD(0, rs));
+                    const int32_t inst = RT_REC_STATE(rs);
                     const uint32_t key = __float_as_uint(meta.z);
                     const int bounce = DIEL ? (__float_as_int(meta.y) & (kPoolInsideBit - 1)) : __float_as_int(meta.y);
                     bool insideGlass = DIEL && (__float_as_int(meta.y) & kPoolInsideBit) != 0;
@@ -280,9 +284,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                     ended = true;
                     if (lane < n) {
                         const int rs = s;
-                        const float4 meta = recLoad(RT_HOT(2, rs));
-                        const int32_t inst = __float_as_int(meta.w);
+                        const int32_t inst = RT_REC_STATE(rs);
                         if (inst == kPoolMiss) {
+                            const float4 meta = recLoad(RT_HOT(2, rs));
                             const float4 r0 = recLoad(RT_HOT(0, rs)), r1 = recLoad(RT_HOT(1, rs)), e4 = recLoad(RT_COLD(0, rs)), l4 = recLoad(RT_COLD(1, rs));
                             const int bounce = DIEL ? (__float_as_int(meta.y) & (kPoolInsideBit - 1)) : __float_as_int(meta.y);
                             V3 L = v3(l4.x, l4.y, l4.z) + v3(e4.x, e4.y, e4.z) * shadeMiss(sky, v3(r0.w, r1.x, r1.y));
@@ -530,7 +534,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     {
         // measured optima of the three benchmark scenes: shading is cheap here (full waves), so
         // lanes are refilled earlier than in kFast; small scenes (same criterion as kFast's) walk on with few lanes
-        const bool allHot = fs.nBlasNodes + (size_t)fs.nTlasNodes <= (size_t)kHotNodes;
+        const bool allHot = fs.nBlasNodes + (size_t)fs.nTlasNodes <= (size_t)kPoolHotNodes;
         if (cfg.refillBelow == 0) cfg.refillBelow = 40;
         if (cfg.nodeMin == 0) cfg.nodeMin = allHot ? 12 : 16;
     }
@@ -628,7 +632,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         if ((e = hipMemcpyAsync(h, fs.stats.p, sizeof(h), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
         const char* names[12] = {"hitPass", "nodeStep", "instEnter", "triLeaf(slot boxes)", "triTest", "publish", "leafPhase(trav lanes)", "nodeLoop(trav lanes)", "endStartPass",
-                                 "nodeStep, stale", "instEnter, stale", "nodeStep, no child"};
+                                 "nodeStep, stale", "instEnter, stale", "nodeStep, node in LDS"};
         for (int i = 0; i < 12; i++)
             if (h[2 * i]) fprintf(stderr, "[rtamd stats] kPool %-22s executions %12llu  mean active lanes %6.2f\n", names[i], h[2 * i], (double)h[2 * i + 1] / (double)h[2 * i]);
         fprintf(stderr, "[rtamd stats] kPool deepest traversal stack %llu of %d entries in LDS\n", h[24], kLdsStack);

@@ -285,7 +285,7 @@ def test_deep_chain_shaped_tree(gpu_pass, oracle):
 
 
 def test_traversal_stack_overflow_area(gpu_pass, oracle, scene_mesh_small, monkeypatch):
-    """With the LDS part of the traversal stack cut to 16 entries, rays of the mesh scene move
+    """With the LDS part of the traversal stack cut to 12 entries, rays of the mesh scene move
     chunks of their stack to the overflow area in HBM and back; the image must not change."""
     buf, frame, sky = scene_mesh_small
     w, h = 96, 54
@@ -293,7 +293,7 @@ def test_traversal_stack_overflow_area(gpu_pass, oracle, scene_mesh_small, monke
     gpu_pass.SetSkyBox(sky)
     kw = dict(mode=T.MODE_PT, spp=4, max_bounces=4, seed=1234)
     o = oracle.render(buf, frame, w, h, sky=sky, mode=1, spp=4, max_bounces=4, seed=1234)
-    monkeypatch.setenv("RTAMD_STACK_LIMIT", "16")
+    monkeypatch.setenv("RTAMD_STACK_LIMIT", "12")
     g = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, **kw)
     monkeypatch.delenv("RTAMD_STACK_LIMIT")
     assert np.array_equal(g["ids"], o["ids"]) and np.array_equal(g["t"], o["t"], equal_nan=True)
