@@ -46,6 +46,11 @@ constexpr int kPoolChunk = 256;      // path indices a wave takes from the batch
 #ifndef RT_POOL_HOT_NODES
 #define RT_POOL_HOT_NODES 456
 #endif
+#ifndef RT_POOL_HOT_NODES_BIG
+#define RT_POOL_HOT_NODES_BIG 164
+#endif
+constexpr int kPoolHotNodesBig = RT_POOL_HOT_NODES_BIG;   // the variant for large scenes: 18 KiB of nodes, and 32 KiB for the paths' throughput words instead
+constexpr int kPoolBigSceneNodes = 65536;                 // scenes with more nodes than this run the large-scene variant (RTAMD_POOL_BIG=0/1 overrides)
 constexpr int kPoolHotNodes = RT_POOL_HOT_NODES;   // LDS: 64 KiB stacks + 6 KiB queues + 40 KiB hit results and states + 50 KiB nodes
 
 struct PoolBatch {
@@ -101,7 +106,10 @@ __device__ __forceinline__ void poolHandOver(const RenderArgs& a, uint32_t p) {
 // DIEL = true (RTAMD_FLAG_DIELECTRICS): glass objects refract; bit 16 of a record's bounce word says that
 // the path is inside glass, and such a ray tests triangles from both sides.
 constexpr int32_t kPoolInsideBit = 1 << 16;
-template <bool STATS, bool DIEL = false>
+// BIG = true: the variant for scenes whose nodes are far too many for LDS anyway (the LDS copy of the top of the
+// trees measured worth 0.3 % there between 160 and 456 nodes): most of the node copy's room holds piece cold 0
+// of every record instead, which takes one more read and one more write request per ray segment from L2.
+template <bool STATS, bool DIEL = false, bool BIG = false>
 __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene sc, Sky sky, RenderArgs a, PoolBatch b, int refillBelow,
                                                                        int nodeMin, int leafGroupMin, int stackLimit, int poolSlots,
                                                                        unsigned long long* stats) {
@@ -115,7 +123,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
     } while (0)
 #define RT_STAT2(slot, cond) RT_STAT(slot, cond)
     __shared__ int32_t ldsStack[kLdsStack][kBlockThreads];
-    __shared__ float4 ldsNodes[kPoolHotNodes * kHotStride];
+    __shared__ float4 ldsNodes[(BIG ? kPoolHotNodesBig : kPoolHotNodes) * kHotStride];
+    __shared__ float4 ldsCold0[BIG ? (kBlockThreads / 64) * kPoolSlots : 1];
     __shared__ uint8_t ldsQueues[kBlockThreads / 64][3][kPoolQueue];
     // what a finished ray leaves for the shading pass stays in LDS (written by one lane of the wave, read by another):
     // t, u, v, triangle of the hit, and the record's state
@@ -135,6 +144,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
 #define RT_HOT(piece, sl) (recHot + (sl) * 4 + (piece))
 #define RT_COLD(piece, sl) (recCold + (sl) * 2 + (piece))
 #define RT_REC_STATE(sl) (ldsState[wave][sl])
+#define RT_COLD0_LD(sl) (BIG ? ldsCold0[wave * kPoolSlots + (sl)] : recLoad(RT_COLD(0, sl)))
+#define RT_COLD0_ST(sl, v) do { if (BIG) ldsCold0[wave * kPoolSlots + (sl)] = (v); else recStore(RT_COLD(0, sl), (v)); } while (0)
 #define RT_REC_BOUNCE(sl) (reinterpret_cast<int32_t*>(RT_HOT(2, sl))[1])
 #define RT_REC_PIX(sl) (reinterpret_cast<uint32_t*>(RT_COLD(1, sl))[3])
     const unsigned long long totalPaths = (unsigned long long)b.nWork * (unsigned long long)b.nSamples;
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                 if (s >= 0) {
                     const int rs = s;
                     const float4 meta = recLoad(RT_HOT(2, rs));
-                    const float4 r0 = recLoad(RT_HOT(0, rs)), r1 = recLoad(RT_HOT(1, rs)), h4 = ldsHit[wave][rs], e4 = recLoad(RT_COLD(0, rs));
+                    const float4 r0 = recLoad(RT_HOT(0, rs)), r1 = recLoad(RT_HOT(1, rs)), h4 = ldsHit[wave][rs], e4 = RT_COLD0_LD(rs);
                     const int32_t inst = RT_REC_STATE(rs);
                     const uint32_t key = __float_as_uint(meta.z);
                     const int bounce = DIEL ? (__float_as_int(meta.y) & (kPoolInsideBit - 1)) : __float_as_int(meta.y);
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                             recStore(RT_HOT(0, rs), make_float4(next.origin.x, next.origin.y, next.origin.z, next.direction.x));
                             recStore(RT_HOT(1, rs), make_float4(next.direction.y, next.direction.z, next.invDir.x, next.invDir.y));
                             recStore(RT_HOT(2, rs), make_float4(next.invDir.z, __int_as_float((bounce + 1) | (insideGlass ? kPoolInsideBit : 0)), meta.z, meta.w));
-                            recStore(RT_COLD(0, rs), make_float4(energy.x, energy.y, energy.z, e4.w));
+                            RT_COLD0_ST(rs, make_float4(energy.x, energy.y, energy.z, e4.w));
                             if (lit) {
                                 const float4 l4 = recLoad(RT_COLD(1, rs));
                                 const V3 L = v3(l4.x, l4.y, l4.z) + gain;
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                         const int32_t inst = RT_REC_STATE(rs);
                         if (inst == kPoolMiss) {
                             const float4 meta = recLoad(RT_HOT(2, rs));
-                            const float4 r0 = recLoad(RT_HOT(0, rs)), r1 = recLoad(RT_HOT(1, rs)), e4 = recLoad(RT_COLD(0, rs)), l4 = recLoad(RT_COLD(1, rs));
+                            const float4 r0 = recLoad(RT_HOT(0, rs)), r1 = recLoad(RT_HOT(1, rs)), e4 = RT_COLD0_LD(rs), l4 = recLoad(RT_COLD(1, rs));
                             const int bounce = DIEL ? (__float_as_int(meta.y) & (kPoolInsideBit - 1)) : __float_as_int(meta.y);
                             V3 L = v3(l4.x, l4.y, l4.z) + v3(e4.x, e4.y, e4.z) * shadeMiss(sky, v3(r0.w, r1.x, r1.y));
                             poolStoreSample(b.sampleL + __float_as_uint(e4.w), L, bounce + 1);
@@ -348,7 +359,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                                         recStore(RT_HOT(0, rs), make_float4(r.origin.x, r.origin.y, r.origin.z, r.direction.x));
                                         recStore(RT_HOT(1, rs), make_float4(r.direction.y, r.direction.z, r.invDir.x, r.invDir.y));
                                         recStore(RT_HOT(2, rs), make_float4(r.invDir.z, __int_as_float(0), __uint_as_float(key), __int_as_float(0)));
-                                        recStore(RT_COLD(0, rs), make_float4(1.f, 1.f, 1.f, __uint_as_float((uint32_t)p)));
+                                        RT_COLD0_ST(rs, make_float4(1.f, 1.f, 1.f, __uint_as_float((uint32_t)p)));
                                         recStore(RT_COLD(1, rs), make_float4(0.f, 0.f, 0.f, __uint_as_float(pix)));
                                         live = true;
                                     }
@@ -422,6 +433,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
 #undef RT_HOT
 #undef RT_COLD
 #undef RT_REC_STATE
+#undef RT_COLD0_LD
+#undef RT_COLD0_ST
 #undef RT_REC_PIX
 #undef RT_REC_BOUNCE
     if (STATS) {
@@ -531,6 +544,8 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         numCU = prop.multiProcessorCount;
     }
     FastLaunchConfig cfg = fastLaunchConfig();
+    bool big = fs.nBlasNodes + (size_t)fs.nTlasNodes > (size_t)kPoolBigSceneNodes && !(a.flags & RTAMD_FLAG_DIELECTRICS);
+    if (const char* bv = getenv("RTAMD_POOL_BIG")) big = atoi(bv) != 0 && !(a.flags & RTAMD_FLAG_DIELECTRICS);
     {
         // measured optima of the three benchmark scenes: shading is cheap here (full waves), so
         // lanes are refilled earlier than in kFast; small scenes (same criterion as kFast's) walk on with few lanes
@@ -604,7 +619,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             b.sampleBase = s0;
             b.nSamples = a.spp - s0 < (int)samplesPerBatch ? a.spp - s0 : (int)samplesPerBatch;
             b.firstBatch = s0 == 0; b.lastBatch = s0 + b.nSamples >= a.spp;
-            hotRanges(kPoolHotNodes, b.hotTlas, b.hotBlas);
+            hotRanges(big ? kPoolHotNodesBig : kPoolHotNodes, b.hotTlas, b.hotBlas);
             const unsigned long long total = (unsigned long long)b.nWork * (unsigned long long)b.nSamples;
             if ((e = hipMemsetAsync(a.rayCount + 1, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
             long long blocksNeeded = (long long)((total + kBlockThreads - 1) / kBlockThreads);
@@ -618,9 +633,13 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             }
             if ((e = ph.eventsFor(ph.nTimed)) != hipSuccess) return e;
             if ((e = hipEventRecord(ph.evBegin[ph.nTimed], stream)) != hipSuccess) return e;
-            if (a.flags & RTAMD_FLAG_DIELECTRICS) hipLaunchKernelGGL((kPool<false, true>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots, (unsigned long long*)nullptr);
-            else if (cfg.stats) hipLaunchKernelGGL(kPool<true>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots, fs.stats.p);
-            else hipLaunchKernelGGL(kPool<false>, dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots, (unsigned long long*)nullptr);
+#define RT_LAUNCH_POOL(S_, D_, B_, stats_) hipLaunchKernelGGL((kPool<S_, D_, B_>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots, stats_)
+            if (a.flags & RTAMD_FLAG_DIELECTRICS) RT_LAUNCH_POOL(false, true, false, (unsigned long long*)nullptr);
+            else if (cfg.stats && big) RT_LAUNCH_POOL(true, false, true, fs.stats.p);
+            else if (cfg.stats) RT_LAUNCH_POOL(true, false, false, fs.stats.p);
+            else if (big) RT_LAUNCH_POOL(false, false, true, (unsigned long long*)nullptr);
+            else RT_LAUNCH_POOL(false, false, false, (unsigned long long*)nullptr);
+#undef RT_LAUNCH_POOL
             if ((e = hipEventRecord(ph.evEnd[ph.nTimed++], stream)) != hipSuccess) return e;
             hipLaunchKernelGGL(kPoolSum, dim3((b.nWork + 255) / 256), dim3(256), 0, stream, sc, a, b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
