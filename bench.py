@@ -120,13 +120,14 @@ def roofline_for(rt, frame, W, Hh, out, args, workload, spp, kernel_ms_avg, sum_
                                       "what": "VALU wave instructions of the step (PMC SQ_INSTS_VALU) / kernel time against 1024 SIMDs x 1 per 4 cycles"}
         if pmc.get("l2_read_bytes_per_step") and ceil:
             level = "l2_0.2MB" if workload == "spheres" else "mall_84MB"
-            peak = ceil.get(level, {}).get("gather_node_GBps")
+            # one node of the micro-benchmark = one 128-byte line request (it reads 112 bytes of it)
+            peak = ceil.get(level, {}).get("gather_nodes_per_s", 0.0) * 128.0 / 1e9
             if peak:
                 gbs = pmc["l2_read_bytes_per_step"] / secs / 1e9
                 ceilings["l2_gather"] = {"achieved": gbs, "peak": peak, "unit": "GB/s", "frac": gbs / peak,
                                          "write_requests_per_s": pmc.get("l2_write_requests_per_step", 0.0) / secs,
                                          "what": f"L1->L2 read bytes of the step (PMC TCP_TCC_READ_REQ x 128 B) / kernel time against the measured rate of "
-                                                 f"per-lane 128-byte line gathers from a {level.split('_')[1]} working set (tools/l2_stream.hip)"}
+                                                 f"per-lane 128-byte line gathers from a {level.split('_')[1]} working set (tools/l2_stream.hip: lines per second x 128 B)"}
     # the ceiling that binds is the one with the largest fraction; FP32 VALU is what the contract prices
     binding = max(ceilings.items(), key=lambda kv: kv[1]["frac"])[0]
     v = ceilings["fp32_valu"]
