@@ -284,7 +284,9 @@ int rtamd_last_trace_kernel_ms(const rtamd_ctx* ctx, float* trace_ms);
 
 /* The part of that time spent in the hand-over pass (pixels the production kernel
  * could not settle itself and gave to the reference-order kernel), and how many
- * pixels that was.  No counterpart in the reference. */
+ * pixels that was — plus, in PT mode, the single paths the path-tracing kernel
+ * passed on between its launches (their time is part of kernel_ms, not of
+ * handover_ms).  No counterpart in the reference. */
 int rtamd_last_handover_stats(const rtamd_ctx* ctx, float* handover_ms, int32_t* pixels);
 
 /* Presentation step of the reference: AddShader's `Blend SrcAlpha One`

@@ -169,6 +169,32 @@ __device__ __forceinline__ Surf refResolve(const RefScene& sc, const Ray& ray, c
     return s;
 }
 
+// One path of PT mode in reference order: sample `sample` (counted from 0 over the whole render) of pixel (x, y).
+__device__ __forceinline__ V3 refTracePath(const RefScene& sc, const Sky& sky, const RenderArgs& a, int x, int y, int sample,
+                                           int32_t* blasStack, LocalCounters& cnt) {
+    const size_t pix = (size_t)y * a.width + x;
+    uint32_t key = rngKey(a.seedHi, a.seedLo, (uint32_t)pix, (uint32_t)sample);
+    float jx = a.cb.PixelOffset[0], jy = a.cb.PixelOffset[1];
+    if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
+    Ray ray = cameraRay(a.cb, pixelToNdc(x, jx, a.width), pixelToNdc(y, jy, a.height));
+    V3 L = v3(0, 0, 0), energy = v3(1, 1, 1);
+    const bool dielectrics = (a.flags & RTAMD_FLAG_DIELECTRICS) != 0;
+    bool insideGlass = false;
+    for (int b = 0;; b++) {
+        HitRec h = refIntersectTlas(sc, ray, blasStack, cnt, insideGlass);
+        if (!(h.t < RT_INF)) { L = L + energy * shadeMiss(sky, ray.direction); break; }
+        Surf sf = refResolve(sc, ray, h);
+        L = L + energy * sf.emission;
+        if (b >= a.maxBounces) break;
+        V3 org, dir;
+        const bool goOn = dielectrics ? scatterSurface<true>(sf, ray.direction, key, (uint32_t)b, energy, org, dir, insideGlass)
+                                      : scatterSurface<false>(sf, ray.direction, key, (uint32_t)b, energy, org, dir, insideGlass);
+        if (!goOn) break;
+        ray = makeRay(org, dir);
+    }
+    return L;
+}
+
 __device__ __forceinline__ unsigned long long waveSum(uint32_t v) {
     unsigned long long s = v;
 #pragma unroll
@@ -242,28 +268,7 @@ __global__ __launch_bounds__(64) void kFaithful(RefScene sc, Sky sky, RenderArgs
         }
         if (a.mode == RTAMD_MODE_PT) {
             V3 sum = v3(0, 0, 0);
-            for (int s = sFirst; s < sLast; s++) {
-                uint32_t key = rngKey(a.seedHi, a.seedLo, (uint32_t)pix, (uint32_t)(a.sampleOffset + s));
-                float jx = a.cb.PixelOffset[0], jy = a.cb.PixelOffset[1];
-                if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
-                Ray ray = cameraRay(a.cb, pixelToNdc(x, jx, a.width), pixelToNdc(y, jy, a.height));
-                V3 L = v3(0, 0, 0), energy = v3(1, 1, 1);
-                const bool dielectrics = (a.flags & RTAMD_FLAG_DIELECTRICS) != 0;
-                bool insideGlass = false;
-                for (int b = 0;; b++) {
-                    HitRec h = refIntersectTlas(sc, ray, blasStack, cnt, insideGlass);
-                    if (!(h.t < RT_INF)) { L = L + energy * shadeMiss(sky, ray.direction); break; }
-                    Surf sf = refResolve(sc, ray, h);
-                    L = L + energy * sf.emission;
-                    if (b >= a.maxBounces) break;
-                    V3 org, dir;
-                    const bool goOn = dielectrics ? scatterSurface<true>(sf, ray.direction, key, (uint32_t)b, energy, org, dir, insideGlass)
-                                                  : scatterSurface<false>(sf, ray.direction, key, (uint32_t)b, energy, org, dir, insideGlass);
-                    if (!goOn) break;
-                    ray = makeRay(org, dir);
-                }
-                sum = sum + L;
-            }
+            for (int s = sFirst; s < sLast; s++) sum = sum + refTracePath(sc, sky, a, x, y, a.sampleOffset + s, blasStack, cnt);
             if (sampleOut) sampleOut[gi] = make_float4(sum.x, sum.y, sum.z, 0.f);
             else writePathPixel(a, pix, sum);
         }
@@ -286,6 +291,31 @@ __global__ __launch_bounds__(64) void kFaithful(RefScene sc, Sky sky, RenderArgs
             atomicAdd(&a.counters->overflow, ovf);
         }
         if (ovf) atomicOr(a.errorFlag, 1);
+    }
+}
+
+// A path the path-pool kernel could not settle (an order-ambiguous hit, a ray with a zero direction component, a
+// stack beyond its overflow area): traced here in reference order, its radiance and segment count put where the
+// pool kernel would have put them, before the batch's samples are added up.
+struct PathRedo { uint32_t slot; uint32_t pixel; int32_t sample; };
+// One path per wave (lane 0; the nested loops of the reference order serialise lanes anyway); a fixed grid strides
+// over however many paths the batch listed.  `count` may exceed `cap`: the pool kernel falls back to handing the
+// whole pixel over once the list is full.
+__global__ __launch_bounds__(64) void kFaithfulPaths(RefScene sc, Sky sky, RenderArgs a, const PathRedo* list, const int32_t* count, int cap,
+                                                     float4* sampleOut) {
+    int n = *count;
+    if (n > cap) n = cap;
+    int32_t blasStack[kRefBlasStack];
+    uint32_t overflow = 0;
+    if (threadIdx.x == 0) {
+        for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
+            const PathRedo r = list[i];
+            LocalCounters cnt = {0, 0, 0, 0, 0, 0, 0, 0};
+            const V3 L = refTracePath(sc, sky, a, (int)(r.pixel % (uint32_t)a.width), (int)(r.pixel / (uint32_t)a.width), r.sample, blasStack, cnt);
+            sampleOut[r.slot] = make_float4(L.x, L.y, L.z, __uint_as_float(cnt.rays));
+            overflow += cnt.overflow;
+        }
+        if (overflow) atomicOr(a.errorFlag, 1);
     }
 }
 

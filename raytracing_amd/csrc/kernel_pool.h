@@ -65,6 +65,11 @@ struct PoolBatch {
     int32_t firstBatch, lastBatch;
     int32_t hotTlas, hotBlas;     // hot-node ranges for kPoolHotNodes
     int32_t chunk;                // path indices a wave takes at a time
+    // paths this kernel cannot settle go to the reference-order kernel one by one (kFaithfulPaths, between this
+    // launch and the summation); when the list is full the whole pixel is handed over instead
+    PathRedo* pathList;
+    int32_t* pathCount;           // [0] entries of this batch (reset by kPoolSum), [1] total of the render
+    int32_t pathCap;
 };
 
 // work item -> pixel; false when the item lies outside the image or the requested rectangle
@@ -89,6 +94,19 @@ __device__ __forceinline__ void poolStoreSample(float4* dst, V3 L, int segments)
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 v = {L.x, L.y, L.z, __int_as_float(segments)};
     __builtin_nontemporal_store(v, reinterpret_cast<f4*>(dst));
+}
+
+// path `slot` of the batch = sample `slot / nWork` of pixel `pix`
+__device__ __forceinline__ void poolHandOver(const RenderArgs& a, uint32_t p);
+__device__ __forceinline__ void poolHandOverPath(const RenderArgs& a, const PoolBatch& b, uint32_t slot, uint32_t pix) {
+    const int i = atomicAdd(b.pathCount, 1);
+    if (i < b.pathCap) {
+        PathRedo r;
+        r.slot = slot; r.pixel = pix;
+        r.sample = a.sampleOffset + b.sampleBase + (int32_t)(slot / b.nWork);
+        b.pathList[i] = r;
+        atomicAdd(b.pathCount + 1, 1);
+    } else poolHandOver(a, pix);
 }
 
 __device__ __forceinline__ void poolHandOver(const RenderArgs& a, uint32_t p) {
@@ -259,7 +277,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                     if (bounce < a.maxBounces && scatterSurface<DIEL>(sf, w.direction, key, (uint32_t)bounce, energy, org, dir, insideGlass)) {
                         const Ray next = makeRay(org, dir);
                         write = false;
-                        if (rayDegenerate(next)) { poolHandOver(a, RT_REC_PIX(rs)); ended = true; }
+                        if (rayDegenerate(next)) { poolHandOverPath(a, b, __float_as_uint(e4.w), RT_REC_PIX(rs)); ended = true; }
                         else {
                             recStore(RT_HOT(0, rs), make_float4(next.origin.x, next.origin.y, next.origin.z, next.direction.x));
                             recStore(RT_HOT(1, rs), make_float4(next.direction.y, next.direction.z, next.invDir.x, next.invDir.y));
@@ -303,7 +321,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                             V3 L = v3(l4.x, l4.y, l4.z) + v3(e4.x, e4.y, e4.z) * shadeMiss(sky, v3(r0.w, r1.x, r1.y));
                             poolStoreSample(b.sampleL + __float_as_uint(e4.w), L, bounce + 1);
                         } else if (inst == kPoolUnsettled) {
-                            poolHandOver(a, RT_REC_PIX(rs));
+                            const float4 e4 = RT_COLD0_LD(rs);
+                            poolHandOverPath(a, b, __float_as_uint(e4.w), RT_REC_PIX(rs));
                         }
                     }
                 }
@@ -354,7 +373,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                                     float jx = a.cb.PixelOffset[0], jy = a.cb.PixelOffset[1];
                                     if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
                                     const Ray r = cameraRay(a.cb, pixelToNdc(x, jx, a.width), pixelToNdc(y, jy, a.height));
-                                    if (rayDegenerate(r)) poolHandOver(a, pix);
+                                    if (rayDegenerate(r)) poolHandOverPath(a, b, (uint32_t)p, pix);
                                     else {
                                         recStore(RT_HOT(0, rs), make_float4(r.origin.x, r.origin.y, r.origin.z, r.direction.x));
                                         recStore(RT_HOT(1, rs), make_float4(r.direction.y, r.direction.z, r.invDir.x, r.invDir.y));
@@ -450,6 +469,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
 // the pixel and counts its ray segments.
 __global__ __launch_bounds__(256) void kPoolSum(FastScene sc, RenderArgs a, PoolBatch b) {
     const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w == 0) b.pathCount[0] = 0;       // (the next batch starts an empty list)
     unsigned long long rays = 0;
     if (w < b.nWork) {
         int x, y;
@@ -481,11 +501,13 @@ __global__ __launch_bounds__(256) void kPoolSum(FastScene sc, RenderArgs a, Pool
 struct PoolHost {
     DBuf<PoolRec> recs;
     DBuf<float4> sampleL, runSum;
+    DBuf<PathRedo> pathList;
+    static constexpr int kPathCap = 65536;
     // device time of the kPool launches of the last render: one pair of events per launch
     std::vector<hipEvent_t> evBegin, evEnd;
     int nTimed = 0;
     void release() {
-        recs.release(); sampleL.release(); runSum.release();
+        recs.release(); sampleL.release(); runSum.release(); pathList.release();
         for (hipEvent_t ev : evBegin) (void)hipEventDestroy(ev);
         for (hipEvent_t ev : evEnd) (void)hipEventDestroy(ev);
         evBegin.clear(); evEnd.clear();
@@ -521,7 +543,8 @@ inline size_t poolMaxPaths() {
 
 // PT-mode render of the pixels selected by `a` (radiance only: the identity of the primary
 // hit comes from kFast<kModePrimary>, launched here first when asked for).
-inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, const RenderArgs& a, hipStream_t stream) {
+inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, const RenderArgs& a, hipStream_t stream,
+                             const RefScene& rsc, int32_t* pathCount) {
     ph.nTimed = 0;
     int tilesX = (a.width + 31) / 32;
     fs.hSuper.clear();
@@ -589,6 +612,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     int poolSlots = kPoolSlots;
     if (const char* sv = getenv("RTAMD_POOL_SLOTS")) { int v = atoi(sv); if (v >= 64 && v <= kPoolSlots) poolSlots = v; }
     if ((e = ph.recs.ensure((size_t)gridMax * (kBlockThreads / 64) * kPoolSlots)) != hipSuccess) return e;
+    if ((e = ph.pathList.ensure((size_t)PoolHost::kPathCap)) != hipSuccess) return e;
     size_t tilesPerChunk = 0, workPerChunk = 0, samplesPerBatch = 0;
     for (size_t cap = poolMaxPaths();; cap /= 2) {
         tilesPerChunk = cap / 1024;
@@ -619,6 +643,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             b.sampleBase = s0;
             b.nSamples = a.spp - s0 < (int)samplesPerBatch ? a.spp - s0 : (int)samplesPerBatch;
             b.firstBatch = s0 == 0; b.lastBatch = s0 + b.nSamples >= a.spp;
+            b.pathList = ph.pathList.p; b.pathCount = pathCount; b.pathCap = PoolHost::kPathCap;
             hotRanges(big ? kPoolHotNodesBig : kPoolHotNodes, b.hotTlas, b.hotBlas);
             const unsigned long long total = (unsigned long long)b.nWork * (unsigned long long)b.nSamples;
             if ((e = hipMemsetAsync(a.rayCount + 1, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
@@ -641,6 +666,8 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             else RT_LAUNCH_POOL(false, false, false, (unsigned long long*)nullptr);
 #undef RT_LAUNCH_POOL
             if ((e = hipEventRecord(ph.evEnd[ph.nTimed++], stream)) != hipSuccess) return e;
+            // the paths the launch could not settle (a few hundred per frame; blocks without a path end at once)
+            hipLaunchKernelGGL(kFaithfulPaths, dim3(2048), dim3(64), 0, stream, rsc, sky, a, (const PathRedo*)b.pathList, (const int32_t*)b.pathCount, b.pathCap, b.sampleL);
             hipLaunchKernelGGL(kPoolSum, dim3((b.nWork + 255) / 256), dim3(256), 0, stream, sc, a, b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }

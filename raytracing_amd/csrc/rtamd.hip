@@ -64,7 +64,8 @@ constexpr size_t kNaOffRayCount = 64;               // ray counter, work-queue h
 constexpr size_t kNaOffErrorFlag = 80;
 constexpr size_t kNaOffRedoCount = 84;
 constexpr size_t kCtrlBytes = 256;                  // the block of small words in front (what a render clears and reads back)
-constexpr size_t kCtrlUsed = 88;
+constexpr size_t kNaOffPathCount = 88;              // paths handed to the reference-order kernel: this batch, whole render (2 x 4 B)
+constexpr size_t kCtrlUsed = 96;
 constexpr size_t kNaOffRedoMask = kCtrlBytes;       // one bit per pixel
 constexpr size_t kNaOffRedoList = kNaOffRedoMask + (size_t)(kNaMaxPixels / 32) * 4;
 constexpr size_t kNaOffSuperTiles = kNaOffRedoList + (size_t)kNaRedoCap * 4;
@@ -587,7 +588,7 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
             // (the path pool needs record and sample buffers sized to the frame: without allocations PT mode
             // runs one path per lane, which gives the same image bit for bit)
             usedPool = a.mode == RTAMD_MODE_PT && rt::fastLaunchConfig().pool && !noAlloc;
-            hipError_t le = usedPool ? rt::launchPool(c->fast, c->pool, sky, a, c->stream)
+            hipError_t le = usedPool ? rt::launchPool(c->fast, c->pool, sky, a, c->stream, rsc, (int32_t*)(ctrl + kNaOffPathCount))
                                      : rt::launchFast(c->fast, sky, a, c->stream, noAlloc ? &lent : nullptr);
             if (le != hipSuccess) return failHip(c, le, "production kernel launch");
         }
@@ -658,7 +659,12 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
     std::memcpy(&hc, c->hostCtrl + kNaOffCounters, sizeof(hc));
     std::memcpy(hr, c->hostCtrl + kNaOffRayCount, sizeof(hr));
     std::memcpy(&herr, c->hostCtrl + kNaOffErrorFlag, sizeof(herr));
-    c->lastRedoPixels = redo;
+    {
+        // pixels of the hand-over pass plus, in PT mode, the single paths the pool kernel passed on batch by batch
+        int32_t paths = 0;
+        std::memcpy(&paths, c->hostCtrl + kNaOffPathCount + 4, sizeof(paths));
+        c->lastRedoPixels = redo + (usedPool ? paths : 0);
+    }
     c->lastHandoverMs = handoverMs;
     if (getenv("RTAMD_VERBOSE"))
         fprintf(stderr, "[rtamd] render %dx%d mode %d: %.3f ms, %d pixels handed to the reference-order kernel; nodes %zu (BLAS %zu), depth BLAS %d TLAS %d, instances %d\n",

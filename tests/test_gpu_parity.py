@@ -356,6 +356,16 @@ def test_both_path_tracing_kernels_give_the_same_image(gpu_pass, oracle, monkeyp
         gpu_pass.Execute(frame, w, h, out_rgba=part, shard_rank=r, shard_count=3, **kw)
         parts += part
     assert _same(parts, pool["rgba"])
+    # the large-scene variant of the pool kernel (throughput words in LDS, few nodes in LDS) is chosen by node
+    # count; forced onto this small scene it must give the same image, also with the stack overflowing
+    monkeypatch.setenv("RTAMD_POOL_BIG", "1")
+    big = gpu_pass.Execute(frame, w, h, out_rgba=True, **kw)
+    monkeypatch.setenv("RTAMD_STACK_LIMIT", "12")
+    big12 = gpu_pass.Execute(frame, w, h, out_rgba=True, **kw)
+    monkeypatch.delenv("RTAMD_STACK_LIMIT")
+    monkeypatch.delenv("RTAMD_POOL_BIG")
+    assert _same(big["rgba"], pool["rgba"]) and big["rays"] == pool["rays"]
+    assert _same(big12["rgba"], pool["rgba"]) and big12["rays"] == pool["rays"]
 
 
 def test_random_frame_sizes_and_parameters(gpu_pass, oracle):
