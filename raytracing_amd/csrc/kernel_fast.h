@@ -264,6 +264,16 @@ struct FastSceneHost {
                     return ~(int32_t)(((triBase + (uint32_t)start) << 2) | (uint32_t)(count - 1));
                 });
                 blasRoot[b] = remap[b][0];
+                // a mesh that fits one leaf (a quad: floors, walls) is entered at that leaf: its root node would only
+                // repeat, on the union of the leaf's slot boxes, the test the slot boxes get anyway
+                {
+                    const WNode& rootNode = hNodes[(size_t)remap[b][0]];
+                    const int32_t ch[4] = {rootNode.child.x, rootNode.child.y, rootNode.child.z, rootNode.child.w};
+                    int used = 0, leaf = 0;
+                    for (int s4 = 0; s4 < 4; s4++)
+                        if (ch[s4] != kEmptyChild) { used++; leaf = ch[s4]; }
+                    if (used == 1 && leaf < 0) blasRoot[b] = leaf;
+                }
             }
         }
         nBlasNodes = hNodes.size() - (size_t)tlasReserve;
