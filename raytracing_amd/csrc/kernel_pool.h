@@ -409,22 +409,49 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             const int want = __popcll(m);
             const int k = want < rayCnt ? want : rayCnt;
             const int mine = __popcll(m & laneBelow);
-            if (idleLane && mine < k) {
-                slot = rayQ[(rayHead + mine) & (kPoolQueue - 1)];
+            if (BIG) {
+                if (idleLane && mine < k) {
+                    slot = rayQ[(rayHead + mine) & (kPoolQueue - 1)];
+                    {
+                        const float4 r0 = recLoad(RT_HOT(0, slot)), r1 = recLoad(RT_HOT(1, slot));
+                        const float iz = RT_HOT(2, slot)->x;
+                        world.origin = v3(r0.x, r0.y, r0.z);
+                        world.direction = v3(r0.w, r1.x, r1.y);
+                        world.invDir = v3(r1.z, r1.w, iz);
+                    }
+                    if (DIEL) twoSided = (RT_REC_BOUNCE(slot) & kPoolInsideBit) != 0;
+                    cur = world;
+                    best.t = RT_INF; best.u = best.v = 0; best.inst = -1; best.tri = -1;
+                    secondT = RT_INF; bestNear = 0.0f;
+                    node = sc.tlasRoot; sp = 0; instSp = kNoInstance; curInst = -1; spilled = 0;
+                    unsettled = false;
+                    trav = true;
+                }
+            } else {
+                // Small-scene variant: every lane reads its path's world-space ray from the record here, the lanes that
+                // go on traversing too (the ray is needed again when the lane leaves an instance): nine registers that
+                // need not survive the shading passes, where the register file is full and the compiler keeps traversal
+                // state in scratch memory (+1.7 % on the spheres scene; the large-scene variant, bound by L2 requests,
+                // loses 1 % to the extra record reads and reads the ray only when a lane takes a new path).
+                const bool taken = idleLane && mine < k;
+                if (taken) slot = rayQ[(rayHead + mine) & (kPoolQueue - 1)];
                 {
-                    const float4 r0 = recLoad(RT_HOT(0, slot)), r1 = recLoad(RT_HOT(1, slot));
-                    const float iz = RT_HOT(2, slot)->x;
+                    const int ws = slot < 0 ? 0 : slot;
+                    const float4 r0 = recLoad(RT_HOT(0, ws)), r1 = recLoad(RT_HOT(1, ws));
+                    const float iz = RT_HOT(2, ws)->x;
                     world.origin = v3(r0.x, r0.y, r0.z);
                     world.direction = v3(r0.w, r1.x, r1.y);
                     world.invDir = v3(r1.z, r1.w, iz);
                 }
-                if (DIEL) twoSided = (RT_REC_BOUNCE(slot) & kPoolInsideBit) != 0;
-                cur = world;
-                best.t = RT_INF; best.u = best.v = 0; best.inst = -1; best.tri = -1;
-                secondT = RT_INF; bestNear = 0.0f;
-                node = sc.tlasRoot; sp = 0; instSp = kNoInstance; curInst = -1; spilled = 0;
-                unsettled = false;
-                trav = true;
+                if (taken) {
+                    if (DIEL) twoSided = (RT_REC_BOUNCE(slot) & kPoolInsideBit) != 0;
+                    cur = world;
+                    best.t = RT_INF; best.u = best.v = 0; best.inst = -1; best.tri = -1;
+                    secondT = RT_INF; bestNear = 0.0f;
+                    node = sc.tlasRoot; sp = 0; instSp = kNoInstance; curInst = -1; spilled = 0;
+                    unsettled = false;
+                    trav = true;
+                }
             }
             rayHead += k;
         }
@@ -644,6 +671,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             b.nSamples = a.spp - s0 < (int)samplesPerBatch ? a.spp - s0 : (int)samplesPerBatch;
             b.firstBatch = s0 == 0; b.lastBatch = s0 + b.nSamples >= a.spp;
             b.pathList = ph.pathList.p; b.pathCount = pathCount; b.pathCap = PoolHost::kPathCap;
+            if (const char* pc = getenv("RTAMD_POOL_PATH_CAP")) { int v = atoi(pc); if (v >= 0 && v < b.pathCap) b.pathCap = v; }      // (tests: a short list)
             hotRanges(big ? kPoolHotNodesBig : kPoolHotNodes, b.hotTlas, b.hotBlas);
             const unsigned long long total = (unsigned long long)b.nWork * (unsigned long long)b.nSamples;
             if ((e = hipMemsetAsync(a.rayCount + 1, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;

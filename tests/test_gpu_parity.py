@@ -368,6 +368,33 @@ def test_both_path_tracing_kernels_give_the_same_image(gpu_pass, oracle, monkeyp
     assert _same(big12["rgba"], pool["rgba"]) and big12["rays"] == pool["rays"]
 
 
+def test_paths_and_pixels_handed_to_the_reference_order_kernel(gpu_pass, oracle, monkeypatch):
+    """Without jitter the centre row and column of the spheres scene's camera have rays with a zero direction
+    component: every sample of those pixels is a path the pool kernel passes on.  With room in the list the
+    paths go one by one; with a list of 5 (or none) the rest fall back to whole pixels.  Same image, same ray
+    count as the oracle either way."""
+    from raytracing_amd import scenes
+    w, h = 192, 108
+    buf, frame, sky = scenes.random_spheres(w, h)
+    gpu_pass.SetScene(buf)
+    gpu_pass.SetSkyBox(sky)
+    kw = dict(mode=T.MODE_PT, spp=5, max_bounces=6, seed=77, flags=T.FLAG_NO_JITTER)
+    o = oracle.render(buf, frame, w, h, sky=sky, mode=1, spp=5, max_bounces=6, seed=77, flags=T.FLAG_NO_JITTER, nthreads=8)
+    handed = []
+    for cap in (None, "5", "0"):
+        if cap is not None:
+            monkeypatch.setenv("RTAMD_POOL_PATH_CAP", cap)
+        g = gpu_pass.Execute(frame, w, h, out_rgba=True, **kw)
+        if cap is not None:
+            monkeypatch.delenv("RTAMD_POOL_PATH_CAP")
+        assert _same(g["rgba"], o["rgba"]), _report("path cap %s" % cap, g, o)
+        assert g["rays"] == o["counters"]["rays"]
+        handed.append(g["handover_pixels"])
+    # paths with room in the list, whole pixels without: at least one of the five samples of every such pixel
+    assert handed[2] >= 100 and handed[2] <= handed[0] <= 5 * handed[2], handed
+    assert handed[2] <= handed[1] <= handed[2] + 5, handed
+
+
 def test_random_frame_sizes_and_parameters(gpu_pass, oracle):
     """Seeded random combinations of odd frame sizes, tile rectangles, shard splits, sample counts and
     offsets, bounce limits and flags, in both modes, against the oracle with the same parameters
