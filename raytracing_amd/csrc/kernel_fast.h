@@ -694,7 +694,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
         // ------------------------------------------------ phase B: traversal
 #define RT_CAN_REFILL (!trav && !(noMoreWork && !pixelActive && !pathActive))
 #define RT_TWO_SIDED (DIEL && insideGlass)
+#define RT_KEEP_HIT(t_, u_, v_, tri_) do { best.u = (u_); best.v = (v_); } while (0)
 #include "traverse_body.inc"
+#undef RT_KEEP_HIT
 #undef RT_TWO_SIDED
 #undef RT_CAN_REFILL
     }
