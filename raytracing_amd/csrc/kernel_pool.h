@@ -68,7 +68,8 @@ struct PoolBatch {
     // paths this kernel cannot settle go to the reference-order kernel one by one (kFaithfulPaths, between this
     // launch and the summation); when the list is full the whole pixel is handed over instead
     PathRedo* pathList;
-    int32_t* pathCount;           // [0] entries of this batch (reset by kPoolSum), [1] total of the render
+    int32_t* pathCount;           // entries of this batch (reset by kPoolSum)
+    int32_t* pathTotal;           // entries of the whole render
     int32_t pathCap;
 };
 
@@ -105,7 +106,7 @@ __device__ __forceinline__ void poolHandOverPath(const RenderArgs& a, const Pool
         r.slot = slot; r.pixel = pix;
         r.sample = a.sampleOffset + b.sampleBase + (int32_t)(slot / b.nWork);
         b.pathList[i] = r;
-        atomicAdd(b.pathCount + 1, 1);
+        atomicAdd(b.pathTotal, 1);
     } else poolHandOver(a, pix);
 }
 
@@ -534,6 +535,20 @@ struct PoolHost {
     DBuf<float4> sampleL, runSum;
     DBuf<PathRedo> pathList;
     static constexpr int kPathCap = 65536;
+    // A frame of several batches alternates between two halves of the sample buffer and of the path list: while
+    // the kernel traces batch i + 1 on the caller's stream, the paths it passed on in batch i are traced and
+    // batch i is added up on a second stream.
+    hipStream_t side = nullptr;
+    hipEvent_t evTraced[2] = {nullptr, nullptr}, evSummed[2] = {nullptr, nullptr};
+    hipError_t sideStream() {
+        if (side) return hipSuccess;
+        hipError_t err = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+        for (int k = 0; k < 2 && err == hipSuccess; k++) {
+            err = hipEventCreateWithFlags(&evTraced[k], hipEventDisableTiming);
+            if (err == hipSuccess) err = hipEventCreateWithFlags(&evSummed[k], hipEventDisableTiming);
+        }
+        return err;
+    }
     // device time of the kPool launches of the last render: one pair of events per launch
     std::vector<hipEvent_t> evBegin, evEnd;
     int nTimed = 0;
@@ -543,6 +558,13 @@ struct PoolHost {
         for (hipEvent_t ev : evEnd) (void)hipEventDestroy(ev);
         evBegin.clear(); evEnd.clear();
         nTimed = 0;
+        for (int k = 0; k < 2; k++) {
+            if (evTraced[k]) (void)hipEventDestroy(evTraced[k]);
+            if (evSummed[k]) (void)hipEventDestroy(evSummed[k]);
+            evTraced[k] = evSummed[k] = nullptr;
+        }
+        if (side) (void)hipStreamDestroy(side);
+        side = nullptr;
     }
     // events of launch i (created on first use)
     hipError_t eventsFor(int i) {
@@ -575,7 +597,7 @@ inline size_t poolMaxPaths() {
 // PT-mode render of the pixels selected by `a` (radiance only: the identity of the primary
 // hit comes from kFast<kModePrimary>, launched here first when asked for).
 inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, const RenderArgs& a, hipStream_t stream,
-                             const RefScene& rsc, int32_t* pathCount) {
+                             const RefScene& rsc, int32_t* pathCountA, int32_t* pathCountB, int32_t* pathTotal) {
     ph.nTimed = 0;
     int tilesX = (a.width + 31) / 32;
     fs.hSuper.clear();
@@ -643,7 +665,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     int poolSlots = kPoolSlots;
     if (const char* sv = getenv("RTAMD_POOL_SLOTS")) { int v = atoi(sv); if (v >= 64 && v <= kPoolSlots) poolSlots = v; }
     if ((e = ph.recs.ensure((size_t)gridMax * (kBlockThreads / 64) * kPoolSlots)) != hipSuccess) return e;
-    if ((e = ph.pathList.ensure((size_t)PoolHost::kPathCap)) != hipSuccess) return e;
+    if ((e = ph.pathList.ensure((size_t)2 * PoolHost::kPathCap)) != hipSuccess) return e;
     size_t tilesPerChunk = 0, workPerChunk = 0, samplesPerBatch = 0;
     for (size_t cap = poolMaxPaths();; cap /= 2) {
         tilesPerChunk = cap / 1024;
@@ -653,7 +675,9 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         samplesPerBatch = cap / workPerChunk;
         if (samplesPerBatch < 1) samplesPerBatch = 1;
         if (samplesPerBatch > (size_t)a.spp) samplesPerBatch = (size_t)a.spp;
-        e = ph.sampleL.ensure(workPerChunk * samplesPerBatch);
+        // (two halves when the frame takes more than one batch)
+        const bool several = workPerChunk < fs.hSuper.size() * 1024 || samplesPerBatch < (size_t)a.spp;
+        e = ph.sampleL.ensure(workPerChunk * samplesPerBatch * (several ? 2 : 1));
         if (e == hipSuccess) e = ph.runSum.ensure(workPerChunk);
         if (e == hipSuccess) break;
         if (e != hipErrorOutOfMemory || cap <= ((size_t)1 << 20)) return e;
@@ -664,20 +688,27 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         if ((e = fs.stats.ensure(25)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(fs.stats.p, 0, 25 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
     }
+    const bool overlap = (workPerChunk < fs.hSuper.size() * 1024 || samplesPerBatch < (size_t)a.spp) && !getenv("RTAMD_POOL_NO_OVERLAP");
+    if (overlap && (e = ph.sideStream()) != hipSuccess) return e;
+    int batchNo = 0;
     for (size_t t0 = 0; t0 < fs.hSuper.size(); t0 += tilesPerChunk) {
         const size_t nt = fs.hSuper.size() - t0 < tilesPerChunk ? fs.hSuper.size() - t0 : tilesPerChunk;
-        for (int s0 = 0; s0 < a.spp; s0 += (int)samplesPerBatch) {
+        for (int s0 = 0; s0 < a.spp; s0 += (int)samplesPerBatch, batchNo++) {
+            const int half = overlap ? (batchNo & 1) : 0;
             PoolBatch b;
-            b.recs = ph.recs.p; b.sampleL = ph.sampleL.p; b.runSum = ph.runSum.p;
+            b.recs = ph.recs.p; b.sampleL = ph.sampleL.p + (size_t)half * workPerChunk * samplesPerBatch; b.runSum = ph.runSum.p;
             b.next = a.rayCount + 1;
             b.nWork = (uint32_t)(nt * 1024); b.superBase = (int32_t)t0;
             b.sampleBase = s0;
             b.nSamples = a.spp - s0 < (int)samplesPerBatch ? a.spp - s0 : (int)samplesPerBatch;
             b.firstBatch = s0 == 0; b.lastBatch = s0 + b.nSamples >= a.spp;
-            b.pathList = ph.pathList.p; b.pathCount = pathCount; b.pathCap = PoolHost::kPathCap;
+            b.pathList = ph.pathList.p + (size_t)half * PoolHost::kPathCap; b.pathCount = half ? pathCountB : pathCountA; b.pathTotal = pathTotal;
+            b.pathCap = PoolHost::kPathCap;
             if (const char* pc = getenv("RTAMD_POOL_PATH_CAP")) { int v = atoi(pc); if (v >= 0 && v < b.pathCap) b.pathCap = v; }      // (tests: a short list)
             hotRanges(big ? kPoolHotNodesBig : kPoolHotNodes, b.hotTlas, b.hotBlas);
             const unsigned long long total = (unsigned long long)b.nWork * (unsigned long long)b.nSamples;
+            // this half of the buffers is free once the batch before the last has been added up
+            if (overlap && batchNo >= 2 && (e = hipStreamWaitEvent(stream, ph.evSummed[half], 0)) != hipSuccess) return e;
             if ((e = hipMemsetAsync(a.rayCount + 1, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
             long long blocksNeeded = (long long)((total + kBlockThreads - 1) / kBlockThreads);
             int grid = blocksNeeded < gridMax ? (int)blocksNeeded : gridMax;
@@ -698,12 +729,23 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             else RT_LAUNCH_POOL(false, false, false, (unsigned long long*)nullptr);
 #undef RT_LAUNCH_POOL
             if ((e = hipEventRecord(ph.evEnd[ph.nTimed++], stream)) != hipSuccess) return e;
-            // the paths the launch could not settle (a few hundred per frame; blocks without a path end at once)
-            hipLaunchKernelGGL(kFaithfulPaths, dim3(2048), dim3(64), 0, stream, rsc, sky, a, (const PathRedo*)b.pathList, (const int32_t*)b.pathCount, b.pathCap, b.sampleL);
-            hipLaunchKernelGGL(kPoolSum, dim3((b.nWork + 255) / 256), dim3(256), 0, stream, sc, a, b);
+            // the paths the launch could not settle (a few hundred per frame; blocks without a path end at once), then
+            // the summation: behind the launch on the second stream when more batches follow on this one
+            hipStream_t after = stream;
+            if (overlap) {
+                if ((e = hipEventRecord(ph.evTraced[half], stream)) != hipSuccess) return e;
+                if ((e = hipStreamWaitEvent(ph.side, ph.evTraced[half], 0)) != hipSuccess) return e;
+                after = ph.side;
+            }
+            hipLaunchKernelGGL(kFaithfulPaths, dim3(2048), dim3(64), 0, after, rsc, sky, a, (const PathRedo*)b.pathList, (const int32_t*)b.pathCount, b.pathCap, b.sampleL);
+            hipLaunchKernelGGL(kPoolSum, dim3((b.nWork + 255) / 256), dim3(256), 0, after, sc, a, b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (overlap && (e = hipEventRecord(ph.evSummed[half], ph.side)) != hipSuccess) return e;
         }
     }
+    // the caller's stream goes on when the last batch has been added up (the batches before it were added up earlier
+    // on the same second stream)
+    if (overlap && batchNo > 0 && (e = hipStreamWaitEvent(stream, ph.evSummed[(batchNo - 1) & 1], 0)) != hipSuccess) return e;
     if (cfg.stats) {
         // diagnostic build: per-phase execution counts and active lanes of the whole render, to stderr
         unsigned long long h[25];

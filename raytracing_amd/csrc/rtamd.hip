@@ -64,8 +64,8 @@ constexpr size_t kNaOffRayCount = 64;               // ray counter, work-queue h
 constexpr size_t kNaOffErrorFlag = 80;
 constexpr size_t kNaOffRedoCount = 84;
 constexpr size_t kCtrlBytes = 256;                  // the block of small words in front (what a render clears and reads back)
-constexpr size_t kNaOffPathCount = 88;              // paths handed to the reference-order kernel: this batch, whole render (2 x 4 B)
-constexpr size_t kCtrlUsed = 96;
+constexpr size_t kNaOffPathCount = 88;              // paths handed to the reference-order kernel: this batch, whole render, the batch in the other half of the buffers (3 x 4 B)
+constexpr size_t kCtrlUsed = 100;
 constexpr size_t kNaOffRedoMask = kCtrlBytes;       // one bit per pixel
 constexpr size_t kNaOffRedoList = kNaOffRedoMask + (size_t)(kNaMaxPixels / 32) * 4;
 constexpr size_t kNaOffSuperTiles = kNaOffRedoList + (size_t)kNaRedoCap * 4;
@@ -588,7 +588,7 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
             // (the path pool needs record and sample buffers sized to the frame: without allocations PT mode
             // runs one path per lane, which gives the same image bit for bit)
             usedPool = a.mode == RTAMD_MODE_PT && rt::fastLaunchConfig().pool && !noAlloc;
-            hipError_t le = usedPool ? rt::launchPool(c->fast, c->pool, sky, a, c->stream, rsc, (int32_t*)(ctrl + kNaOffPathCount))
+            hipError_t le = usedPool ? rt::launchPool(c->fast, c->pool, sky, a, c->stream, rsc, (int32_t*)(ctrl + kNaOffPathCount), (int32_t*)(ctrl + kNaOffPathCount + 8), (int32_t*)(ctrl + kNaOffPathCount + 4))
                                      : rt::launchFast(c->fast, sky, a, c->stream, noAlloc ? &lent : nullptr);
             if (le != hipSuccess) return failHip(c, le, "production kernel launch");
         }

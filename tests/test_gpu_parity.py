@@ -348,8 +348,13 @@ def test_both_path_tracing_kernels_give_the_same_image(gpu_pass, oracle, monkeyp
     # sample buffer limited to 20 000 paths: 3 chunks of tiles x 6 batches of one sample
     monkeypatch.setenv("RTAMD_POOL_MAX_PATHS", "20000")
     small = gpu_pass.Execute(frame, w, h, out_rgba=True, **kw)
+    # (batch i is added up on a second stream while batch i + 1 is traced; RTAMD_POOL_NO_OVERLAP keeps one stream)
+    monkeypatch.setenv("RTAMD_POOL_NO_OVERLAP", "1")
+    serial = gpu_pass.Execute(frame, w, h, out_rgba=True, **kw)
+    monkeypatch.delenv("RTAMD_POOL_NO_OVERLAP")
     monkeypatch.delenv("RTAMD_POOL_MAX_PATHS")
     assert _same(small["rgba"], pool["rgba"]) and small["rays"] == pool["rays"]
+    assert _same(serial["rgba"], pool["rgba"]) and serial["rays"] == pool["rays"]
     parts = np.zeros_like(pool["rgba"])
     for r in range(3):
         part = np.zeros_like(parts)
