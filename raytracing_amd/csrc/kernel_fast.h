@@ -236,6 +236,7 @@ struct FastSceneHost {
             } else {
                 for (int32_t it : tree.order) ft.push_back(ranked[it]);
             }
+            if (ft.size() >= (1u << 28)) { err = "too many triangles for the leaf encoding"; return hipSuccess; }
         }
         // node indices: level by level over all trees (so that a prefix of the BLAS region holds the
         // top of every tree), behind the TLAS region
