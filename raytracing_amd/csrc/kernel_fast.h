@@ -747,8 +747,18 @@ inline FastLaunchConfig fastLaunchConfig() {
 // batches cost little: shade early (refillBelow 32), keep stepping nodes with few lanes (nodeMin 8).
 // A scene whose lower levels live in L2 / HBM pays a memory round trip per node step, which larger
 // batches amortise (48 / 16).  Measured optima of the spheres, mesh and instanced benchmark scenes.
-inline void chooseThresholds(FastLaunchConfig& cfg, const FastSceneHost& fs) {
+// Camera rays and their mirror rays (REF mode, the primary-id pass) are coherent: the lanes of a wave finish
+// together, and waiting for more of them to finish before shading and refilling only lengthens the chain of
+// dependent steps a frame of one or two segments per pixel consists of.  There a lane is served as soon as it is
+// done and node steps go on down to 4 lanes: 1080p REF frames 1.76 -> 1.05 ms (spheres), 1.56 -> 0.82 ms (1M
+// triangles), 4.1 -> 2.0 ms at 3840x2160 against the path-tracing thresholds.
+inline void chooseThresholds(FastLaunchConfig& cfg, const FastSceneHost& fs, int mode) {
     const bool allHot = fs.nBlasNodes + (size_t)fs.nTlasNodes <= (size_t)kHotNodes;
+    if (mode != kModePt) {
+        if (cfg.refillBelow == 0) cfg.refillBelow = 1;
+        if (cfg.nodeMin == 0) cfg.nodeMin = 4;
+        return;
+    }
     if (cfg.refillBelow == 0) cfg.refillBelow = allHot ? 32 : 48;
     if (cfg.nodeMin == 0) cfg.nodeMin = allHot ? 8 : 16;
 }
@@ -788,7 +798,9 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         numCU = prop.multiProcessorCount;
     }
     FastLaunchConfig cfg = fastLaunchConfig();
-    chooseThresholds(cfg, fs);
+    chooseThresholds(cfg, fs, a.mode == RTAMD_MODE_PT ? kModePt : kModeRef);
+    FastLaunchConfig primaryCfg = fastLaunchConfig();
+    chooseThresholds(primaryCfg, fs, kModePrimary);
     long long wavesNeeded = ((long long)fs.hSuper.size() * 1024 + 63) / 64;
     long long blocksNeeded = (wavesNeeded + kBlockThreads / 64 - 1) / (kBlockThreads / 64);
     int grid = numCU * cfg.blocksPerCU;
@@ -820,7 +832,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         // identity of the un-jittered primary hit: a separate, uncounted pass
         RenderArgs ids = a;
         ids.outRgba = nullptr; ids.accum = nullptr; ids.spp = 1;
-        hipLaunchKernelGGL((kFast<kModePrimary, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, ids, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((kFast<kModePrimary, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, ids, primaryCfg.refillBelow, primaryCfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         // the work-queue head and ray counter are shared: reset them between the passes
         if ((e = hipMemsetAsync(a.rayCount, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;

@@ -620,6 +620,8 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         numCU = prop.multiProcessorCount;
     }
     FastLaunchConfig cfg = fastLaunchConfig();
+    FastLaunchConfig primaryCfg = cfg;
+    chooseThresholds(primaryCfg, fs, kModePrimary);
     bool big = fs.nBlasNodes + (size_t)fs.nTlasNodes > (size_t)kPoolBigSceneNodes && !(a.flags & RTAMD_FLAG_DIELECTRICS);
     if (const char* bv = getenv("RTAMD_POOL_BIG")) big = atoi(bv) != 0 && !(a.flags & RTAMD_FLAG_DIELECTRICS);
     {
@@ -653,7 +655,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         long long blocksNeeded = ((long long)fs.hSuper.size() * 1024 + kBlockThreads - 1) / kBlockThreads;
         int grid = numCU * cfg.blocksPerCU;
         if (blocksNeeded < grid) grid = (int)blocksNeeded;
-        hipLaunchKernelGGL((kFast<kModePrimary, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, ids, cfg.refillBelow, cfg.nodeMin,
+        hipLaunchKernelGGL((kFast<kModePrimary, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, ids, primaryCfg.refillBelow, primaryCfg.nodeMin,
                            cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemsetAsync(a.rayCount, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
