@@ -260,6 +260,8 @@ def random_soup(width=640, height=360, seed=0, meshes=4, tris_per_mesh=600, inst
     blas = []
     for m in range(meshes):
         nt = int(rs.randint(tris_per_mesh // 4, tris_per_mesh + 1))
+        if tris_per_mesh <= 8:
+            nt = tris_per_mesh                        # (tiny meshes: exactly that many)
         nv = max(3, nt // 2)
         pos = rs.normal(0, 1, size=(nv, 3)).astype(np.float32)
         pos *= np.float32(10.0 ** rs.uniform(-1, 1))

@@ -185,6 +185,33 @@ def test_random_triangle_soups(gpu_pass, oracle, seed):
     assert g["rays"] == o["counters"]["rays"]
 
 
+@pytest.mark.parametrize("tris_per_mesh", [1, 2, 3, 5, 7])
+@pytest.mark.parametrize("tlas", ["auto", "device"])
+def test_tiny_meshes(gpu_pass, oracle, tris_per_mesh, tlas):
+    """Meshes of 1 to 7 triangles: a mesh that fits one leaf of the rebuilt tree is entered at that leaf
+    (no root node), two-triangle leaves start on a line of their own with a blank record behind a single
+    triangle, and roots have fewer than four children."""
+    from raytracing_amd import scenes
+    w, h = 128, 72
+    buf, frame, sky = scenes.random_soup(w, h, seed=40 + tris_per_mesh, meshes=5, tris_per_mesh=tris_per_mesh, instances=60)
+    gpu_pass.SetTlasBuild(tlas)
+    try:
+        gpu_pass.SetScene(buf)
+        gpu_pass.SetSkyBox(sky)
+        o = oracle.render(buf, frame, w, h, sky=sky, mode=1, spp=3, max_bounces=6, seed=9, nthreads=8)
+        g = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, mode=T.MODE_PT, spp=3, max_bounces=6, seed=9)
+        r = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, mode=T.MODE_REF)
+        ro = oracle.render(buf, frame, w, h, sky=sky, mode=0)
+    finally:
+        gpu_pass.SetTlasBuild("auto")
+    assert (o["ids"][..., 0] >= 0).mean() > 0.02
+    assert _same(g["ids"], o["ids"]), _report("tiny meshes", g, o)
+    assert _same(g["t"], o["t"])
+    assert _same(g["rgba"], o["rgba"]), _report("tiny meshes", g, o)
+    assert g["rays"] == o["counters"]["rays"]
+    assert _same(r["ids"], ro["ids"]) and _same(r["t"], ro["t"]) and _same(r["rgba"], ro["rgba"])
+
+
 @pytest.fixture
 def device_tlas(gpu_pass):
     gpu_pass.SetTlasBuild("device")
