@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--workloads", default="spheres,mesh")
+    ap.add_argument("--mesh-tris", type=int, default=200_000, help="triangle count of the mesh workload (1 000 000: the large-scene variant of the pool kernel)")
     args = ap.parse_args()
     w, h = args.width, args.height
     rt = backend.RayTracingPass(0)
@@ -56,7 +57,7 @@ def main():
             buf, frame0, sky = scenes.random_spheres(w, h)
             centre, radius = np.array([0.0, 0.5, 0.0]), 18.0
         elif wl == "mesh":
-            buf, frame0, sky = scenes.mesh_scene(w, h, target_tris=200_000)
+            buf, frame0, sky = scenes.mesh_scene(w, h, target_tris=args.mesh_tris)
             centre, radius = np.array([0.0, 1.0, 0.0]), 6.0
         else:
             buf, frame0, sky = scenes.instanced_scene(w, h, instances=1250, tris_per_blas=2000)
