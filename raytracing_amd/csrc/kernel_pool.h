@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
     __shared__ int32_t ldsState[kBlockThreads / 64][kPoolSlots];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (the same in every lane: addresses formed from it stay in scalar registers)
     // three queues of record slots, private to the wave:
     uint8_t* const rayQ = ldsQueues[wave][0];     // paths with a ray ready to traverse
     uint8_t* const hitQ = ldsQueues[wave][1];     // paths whose ray hit a surface: to be shaded and scattered
@@ -168,7 +168,8 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
 #define RT_REC_BOUNCE(sl) (reinterpret_cast<int32_t*>(RT_HOT(2, sl))[1])
 #define RT_REC_PIX(sl) (reinterpret_cast<uint32_t*>(RT_COLD(1, sl))[3])
     const unsigned long long totalPaths = (unsigned long long)b.nWork * (unsigned long long)b.nSamples;
-    const unsigned long long laneBelow = (1ull << lane) - 1ull;
+    // number of set bits of a wave mask below this lane (the lane's place among the lanes the mask names)
+#define RT_BELOW(m_) ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m_) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m_), 0u)))
 
     const int hotTlas = b.hotTlas, hotBlas = b.hotBlas;
     for (int i = tid; i < (hotTlas + hotBlas) * 8; i += kBlockThreads) {
@@ -219,10 +220,10 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                 if (toHit) {
                     if (BIG) ldsHit[wave][rs] = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
                     RT_REC_STATE(rs) = best.inst;
-                    hitQ[(hitTail + __popcll(mh & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)slot;
+                    hitQ[(hitTail + RT_BELOW(mh)) & (kPoolQueue - 1)] = (uint8_t)slot;
                 } else {
                     RT_REC_STATE(rs) = (unsettled || amb) ? kPoolUnsettled : kPoolMiss;
-                    endQ[(endTail + __popcll(me & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)slot;
+                    endQ[(endTail + RT_BELOW(me)) & (kPoolQueue - 1)] = (uint8_t)slot;
                 }
                 slot = -1;
             }
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                     nextItem += take;
                     if (nextItem >= b.nWork) { nextItem -= b.nWork; nextSmp++; }      // (a pass takes at most 64 <= nWork paths)
                     if (ended) {
-                        const uint32_t mine = (uint32_t)__popcll(me & laneBelow);
+                        const uint32_t mine = (uint32_t)RT_BELOW(me);
                         const unsigned long long p = base + mine;
                         if (noMoreWork) { }
                         else if (p >= pathEnd) { RT_REC_STATE(s) = kPoolFresh; fresh = true; }
@@ -394,10 +395,10 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             // queue the paths that have a ray to traverse; placeholders go (back) to the end queue
             {
                 const unsigned long long mg = __ballot(goOn);
-                if (goOn) rayQ[(rayTail + __popcll(mg & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)s;
+                if (goOn) rayQ[(rayTail + RT_BELOW(mg)) & (kPoolQueue - 1)] = (uint8_t)s;
                 rayTail += __popcll(mg);
                 const unsigned long long mf = __ballot(fresh);
-                if (fresh) endQ[(endTail + __popcll(mf & laneBelow)) & (kPoolQueue - 1)] = (uint8_t)s;
+                if (fresh) endQ[(endTail + RT_BELOW(mf)) & (kPoolQueue - 1)] = (uint8_t)s;
                 endTail += __popcll(mf);
             }
             __threadfence_block();
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             const int rayCnt = rayTail - rayHead;
             const int want = __popcll(m);
             const int k = want < rayCnt ? want : rayCnt;
-            const int mine = __popcll(m & laneBelow);
+            const int mine = RT_BELOW(m);
             if (BIG) {
                 if (idleLane && mine < k) {
                     slot = rayQ[(rayHead + mine) & (kPoolQueue - 1)];
@@ -484,6 +485,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
 #undef RT_HOT
 #undef RT_COLD
 #undef RT_REC_STATE
+#undef RT_BELOW
 #undef RT_COLD0_LD
 #undef RT_COLD0_ST
 #undef RT_REC_PIX
