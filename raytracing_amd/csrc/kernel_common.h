@@ -61,12 +61,13 @@ __device__ __forceinline__ Ray makeRay(V3 o, V3 d) {          // CreateRay, .com
     return r;
 }
 
-__device__ __forceinline__ Ray cameraRay(const rtamd_frame_cbuffer& cb, float u, float v) {   // .compute:145-157
+// (zero: the z of float4(uv, 0, 1); a caller may pass a zero the compiler cannot see through, see kPool)
+__device__ __forceinline__ Ray cameraRay(const rtamd_frame_cbuffer& cb, float u, float v, float zero = 0.0f) {   // .compute:145-157
     V3 origin = v3(cb.CameraToWorld[12], cb.CameraToWorld[13], cb.CameraToWorld[14]);
     const float* ip = cb.CameraInverseProjection;
-    V3 d = v3(((ip[0] * u + ip[4] * v) + ip[8] * 0.0f) + ip[12],
-              ((ip[1] * u + ip[5] * v) + ip[9] * 0.0f) + ip[13],
-              ((ip[2] * u + ip[6] * v) + ip[10] * 0.0f) + ip[14]);
+    V3 d = v3(((ip[0] * u + ip[4] * v) + ip[8] * zero) + ip[12],
+              ((ip[1] * u + ip[5] * v) + ip[9] * zero) + ip[13],
+              ((ip[2] * u + ip[6] * v) + ip[10] * zero) + ip[14]);
     d = mulDir(cb.CameraToWorld, d);
     d = normalize(d);
     return makeRay(origin, d);

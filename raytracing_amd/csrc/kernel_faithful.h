@@ -297,12 +297,12 @@ __global__ __launch_bounds__(64) void kFaithful(RefScene sc, Sky sky, RenderArgs
 // A path the path-pool kernel could not settle (an order-ambiguous hit, a ray with a zero direction component, a
 // stack beyond its overflow area): traced here in reference order, its radiance and segment count put where the
 // pool kernel would have put them, before the batch's samples are added up.
-struct PathRedo { uint32_t slot; uint32_t pixel; int32_t sample; };
+struct PathRedo { uint32_t slot; uint32_t pixel; int32_t sample; };      // slot = sample in the batch * work items of the batch + work item
 // One path per wave (lane 0; the nested loops of the reference order serialise lanes anyway); a fixed grid strides
 // over however many paths the batch listed.  `count` may exceed `cap`: the pool kernel falls back to handing the
 // whole pixel over once the list is full.
 __global__ __launch_bounds__(64) void kFaithfulPaths(RefScene sc, Sky sky, RenderArgs a, const PathRedo* list, const int32_t* count, int cap,
-                                                     float4* sampleOut) {
+                                                     float4* sampleOut, uint32_t nWork, int32_t firstSample) {
     int n = *count;
     if (n > cap) n = cap;
     int32_t blasStack[kRefBlasStack];
@@ -311,7 +311,8 @@ __global__ __launch_bounds__(64) void kFaithfulPaths(RefScene sc, Sky sky, Rende
         for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
             const PathRedo r = list[i];
             LocalCounters cnt = {0, 0, 0, 0, 0, 0, 0, 0};
-            const V3 L = refTracePath(sc, sky, a, (int)(r.pixel % (uint32_t)a.width), (int)(r.pixel / (uint32_t)a.width), r.sample, blasStack, cnt);
+            const V3 L = refTracePath(sc, sky, a, (int)(r.pixel % (uint32_t)a.width), (int)(r.pixel / (uint32_t)a.width),
+                                      firstSample + (int32_t)(r.slot / nWork), blasStack, cnt);
             sampleOut[r.slot] = make_float4(L.x, L.y, L.z, __uint_as_float(cnt.rays));
             overflow += cnt.overflow;
         }

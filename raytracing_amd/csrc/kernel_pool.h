@@ -104,7 +104,7 @@ __device__ __forceinline__ void poolHandOverPath(const RenderArgs& a, const Pool
     if (i < b.pathCap) {
         PathRedo r;
         r.slot = slot; r.pixel = pix;
-        r.sample = a.sampleOffset + b.sampleBase + (int32_t)(slot / b.nWork);
+        r.sample = 0;        // (kFaithfulPaths works the sample number out of the slot: no division by the batch's width here)
         b.pathList[i] = r;
         atomicAdd(b.pathTotal, 1);
     } else poolHandOver(a, pix);
@@ -374,13 +374,23 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                                     const uint32_t key = rngKey(a.seedHi, a.seedLo, pix, (uint32_t)(a.sampleOffset + b.sampleBase + smp));
                                     float jx = a.cb.PixelOffset[0], jy = a.cb.PixelOffset[1];
                                     if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
-                                    const Ray r = cameraRay(a.cb, pixelToNdc(x, jx, a.width), pixelToNdc(y, jy, a.height));
+                                    // (The frame's size as floats, the zero of the shader's float4(uv, 0, 1) and the 1 of a new path's
+                                    // throughput are the same for every path; formed from values the compiler cannot see
+                                    // through, they are made here, where they are needed, instead of once for the whole kernel
+                                    // in registers that then sit in scratch memory.)
+                                    int wOpaque = a.width, hOpaque = a.height;
+                                    float zeroOpaque = 0.0f;
+                                    asm volatile("" : "+s"(wOpaque), "+s"(hOpaque));
+                                    asm volatile("" : "+v"(zeroOpaque));
+                                    const Ray r = cameraRay(a.cb, pixelToNdc(x, jx, wOpaque), pixelToNdc(y, jy, hOpaque), zeroOpaque);
                                     if (rayDegenerate(r)) poolHandOverPath(a, b, (uint32_t)p, pix);
                                     else {
                                         recStore(RT_HOT(0, rs), make_float4(r.origin.x, r.origin.y, r.origin.z, r.direction.x));
                                         recStore(RT_HOT(1, rs), make_float4(r.direction.y, r.direction.z, r.invDir.x, r.invDir.y));
                                         recStore(RT_HOT(2, rs), make_float4(r.invDir.z, __int_as_float(0), __uint_as_float(key), __int_as_float(0)));
-                                        RT_COLD0_ST(rs, make_float4(1.f, 1.f, 1.f, __uint_as_float((uint32_t)p)));
+                                        float one = 1.0f;
+                                        asm volatile("" : "+v"(one));
+                                        RT_COLD0_ST(rs, make_float4(one, one, one, __uint_as_float((uint32_t)p)));
                                         recStore(RT_COLD(1, rs), make_float4(0.f, 0.f, 0.f, __uint_as_float(pix)));
                                         live = true;
                                     }
@@ -747,7 +757,8 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
                 if ((e = hipStreamWaitEvent(ph.side, ph.evTraced[half], 0)) != hipSuccess) return e;
                 after = ph.side;
             }
-            hipLaunchKernelGGL(kFaithfulPaths, dim3(2048), dim3(64), 0, after, rsc, sky, a, (const PathRedo*)b.pathList, (const int32_t*)b.pathCount, b.pathCap, b.sampleL);
+            hipLaunchKernelGGL(kFaithfulPaths, dim3(2048), dim3(64), 0, after, rsc, sky, a, (const PathRedo*)b.pathList, (const int32_t*)b.pathCount, b.pathCap, b.sampleL,
+                               b.nWork, a.sampleOffset + b.sampleBase);
             hipLaunchKernelGGL(kPoolSum, dim3((b.nWork + 255) / 256), dim3(256), 0, after, sc, a, b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if (overlap && (e = hipEventRecord(ph.evSummed[half], ph.side)) != hipSuccess) return e;
