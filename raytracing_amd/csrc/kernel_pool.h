@@ -218,7 +218,6 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
             if (fin) {
                 const int rs = slot;
                 if (toHit) {
-                    if (BIG) ldsHit[wave][rs] = make_float4(best.t, best.u, best.v, __int_as_float(best.tri));
                     RT_REC_STATE(rs) = best.inst;
                     hitQ[(hitTail + RT_BELOW(mh)) & (kPoolQueue - 1)] = (uint8_t)slot;
                 } else {
@@ -476,8 +475,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
 #define RT_CAN_REFILL (!trav && slot >= 0)
 #define RT_TWO_SIDED (DIEL && twoSided)
         // the closest hit's t, u, v, triangle go straight to the slot's LDS entry (two registers less to carry)
-        // (small-scene variant; in the large-scene one, whose time follows its scratch traffic, the compiler spills more with it)
-#define RT_KEEP_HIT(t_, u_, v_, tri_) do { if (BIG) { best.u = (u_); best.v = (v_); } else ldsHit[wave][slot] = make_float4((t_), (u_), (v_), __int_as_float(tri_)); } while (0)
+#define RT_KEEP_HIT(t_, u_, v_, tri_) do { ldsHit[wave][slot] = make_float4((t_), (u_), (v_), __int_as_float(tri_)); } while (0)
 #include "traverse_body.inc"
 #undef RT_KEEP_HIT
 #undef RT_TWO_SIDED
