@@ -129,7 +129,8 @@ constexpr int32_t kPoolInsideBit = 1 << 16;
 // trees measured worth 0.3 % there between 160 and 456 nodes): most of the node copy's room holds piece cold 0
 // of every record instead, which takes one more read and one more write request per ray segment from L2.
 template <bool STATS, bool DIEL = false, bool BIG = false>
-__global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene sc, Sky sky, RenderArgs a, PoolBatch b, int refillBelow,
+__global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(rtamd_frame_cbuffer camera /* first: read through the argument block's address */,
+                                                                       FastScene sc, Sky sky, RenderArgs a, PoolBatch b, int refillBelow,
                                                                        int nodeMin, int leafGroupMin, int stackLimit, int poolSlots,
                                                                        unsigned long long* stats) {
     unsigned long long st_[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // 12 phases x (executions, lanes)
@@ -371,7 +372,16 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                                 const uint32_t pix = (uint32_t)y * (uint32_t)a.width + (uint32_t)x;
                                 if (!((a.redoMask[pix >> 5] >> (pix & 31u)) & 1u)) {
                                     const uint32_t key = rngKey(a.seedHi, a.seedLo, pix, (uint32_t)(a.sampleOffset + b.sampleBase + smp));
-                                    float jx = a.cb.PixelOffset[0], jy = a.cb.PixelOffset[1];
+                                    // The camera block (two matrices, the pixel offset: 36 scalars) is needed only here, once per
+                                    // new path.  Read as an ordinary argument it would sit in scalar registers for the whole kernel
+                                    // (and, there being too few, shuttle through lanes of a vector register at every use): it is the
+                                    // kernel's first argument and is read here from the argument block itself, through a pointer
+                                    // the compiler cannot see through.
+                                    (void)camera;
+                                    typedef const __attribute__((address_space(4))) rtamd_frame_cbuffer* CameraPtr;
+                                    CameraPtr camPtr = (CameraPtr)__builtin_amdgcn_kernarg_segment_ptr();
+                                    asm volatile("" : "+s"(camPtr));
+                                    float jx = camPtr->PixelOffset[0], jy = camPtr->PixelOffset[1];
                                     if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
                                     // (The frame's size as floats, the zero of the shader's float4(uv, 0, 1) and the 1 of a new path's
                                     // throughput are the same for every path; formed from values the compiler cannot see
@@ -381,7 +391,15 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(FastScene s
                                     float zeroOpaque = 0.0f;
                                     asm volatile("" : "+s"(wOpaque), "+s"(hOpaque));
                                     asm volatile("" : "+v"(zeroOpaque));
-                                    const Ray r = cameraRay(a.cb, pixelToNdc(x, jx, wOpaque), pixelToNdc(y, jy, hOpaque), zeroOpaque);
+                                    // (cameraRay of kernel_common.h, operation for operation, on scalars read from the argument block)
+                                    const float ndcU = pixelToNdc(x, jx, wOpaque), ndcV = pixelToNdc(y, jy, hOpaque);
+                                    V3 cd = v3(((camPtr->CameraInverseProjection[0] * ndcU + camPtr->CameraInverseProjection[4] * ndcV) + camPtr->CameraInverseProjection[8] * zeroOpaque) + camPtr->CameraInverseProjection[12],
+                                               ((camPtr->CameraInverseProjection[1] * ndcU + camPtr->CameraInverseProjection[5] * ndcV) + camPtr->CameraInverseProjection[9] * zeroOpaque) + camPtr->CameraInverseProjection[13],
+                                               ((camPtr->CameraInverseProjection[2] * ndcU + camPtr->CameraInverseProjection[6] * ndcV) + camPtr->CameraInverseProjection[10] * zeroOpaque) + camPtr->CameraInverseProjection[14]);
+                                    cd = v3((camPtr->CameraToWorld[0] * cd.x + camPtr->CameraToWorld[4] * cd.y) + camPtr->CameraToWorld[8] * cd.z,
+                                            (camPtr->CameraToWorld[1] * cd.x + camPtr->CameraToWorld[5] * cd.y) + camPtr->CameraToWorld[9] * cd.z,
+                                            (camPtr->CameraToWorld[2] * cd.x + camPtr->CameraToWorld[6] * cd.y) + camPtr->CameraToWorld[10] * cd.z);
+                                    const Ray r = makeRay(v3(camPtr->CameraToWorld[12], camPtr->CameraToWorld[13], camPtr->CameraToWorld[14]), normalize(cd));
                                     if (rayDegenerate(r)) poolHandOverPath(a, b, (uint32_t)p, pix);
                                     else {
                                         recStore(RT_HOT(0, rs), make_float4(r.origin.x, r.origin.y, r.origin.z, r.direction.x));
@@ -739,7 +757,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             }
             if ((e = ph.eventsFor(ph.nTimed)) != hipSuccess) return e;
             if ((e = hipEventRecord(ph.evBegin[ph.nTimed], stream)) != hipSuccess) return e;
-#define RT_LAUNCH_POOL(S_, D_, B_, stats_) hipLaunchKernelGGL((kPool<S_, D_, B_>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots, stats_)
+#define RT_LAUNCH_POOL(S_, D_, B_, stats_) hipLaunchKernelGGL((kPool<S_, D_, B_>), dim3(grid), dim3(kBlockThreads), 0, stream, a.cb, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots, stats_)
             if (a.flags & RTAMD_FLAG_DIELECTRICS) RT_LAUNCH_POOL(false, true, false, (unsigned long long*)nullptr);
             else if (cfg.stats && big) RT_LAUNCH_POOL(true, false, true, fs.stats.p);
             else if (cfg.stats) RT_LAUNCH_POOL(true, false, false, fs.stats.p);
