@@ -73,6 +73,26 @@ __device__ __forceinline__ Ray cameraRay(const rtamd_frame_cbuffer& cb, float u,
     return makeRay(origin, d);
 }
 
+// The same from the camera block of a kernel whose FIRST argument is that block (by value): read from the argument
+// block itself, through a pointer the compiler cannot see through, at the place where a camera ray is made.  Read
+// as an ordinary argument, the block's 36 scalars sit in scalar registers for the whole kernel, and — there being
+// too few of those in the traversal kernels — are shuttled through lanes of a vector register at every use.
+typedef const __attribute__((address_space(4))) rtamd_frame_cbuffer* CameraArgPtr;
+__device__ __forceinline__ CameraArgPtr cameraArg() {
+    CameraArgPtr p = (CameraArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+__device__ __forceinline__ Ray cameraRayArg(CameraArgPtr c, float u, float v, float zero) {      // cameraRay, operation for operation
+    V3 d = v3(((c->CameraInverseProjection[0] * u + c->CameraInverseProjection[4] * v) + c->CameraInverseProjection[8] * zero) + c->CameraInverseProjection[12],
+              ((c->CameraInverseProjection[1] * u + c->CameraInverseProjection[5] * v) + c->CameraInverseProjection[9] * zero) + c->CameraInverseProjection[13],
+              ((c->CameraInverseProjection[2] * u + c->CameraInverseProjection[6] * v) + c->CameraInverseProjection[10] * zero) + c->CameraInverseProjection[14]);
+    d = v3((c->CameraToWorld[0] * d.x + c->CameraToWorld[4] * d.y) + c->CameraToWorld[8] * d.z,
+           (c->CameraToWorld[1] * d.x + c->CameraToWorld[5] * d.y) + c->CameraToWorld[9] * d.z,
+           (c->CameraToWorld[2] * d.x + c->CameraToWorld[6] * d.y) + c->CameraToWorld[10] * d.z);
+    return makeRay(v3(c->CameraToWorld[12], c->CameraToWorld[13], c->CameraToWorld[14]), normalize(d));
+}
+
 // uv = (id.xy + offset) / (w,h) * 2 - 1.  .compute:439
 __device__ __forceinline__ float pixelToNdc(int p, float offset, int extent) {
     return ((float)p + offset) / (float)extent * 2.0f - 1.0f;

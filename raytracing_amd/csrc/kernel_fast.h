@@ -502,7 +502,7 @@ __device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world
 // DIEL = true (PT mode with RTAMD_FLAG_DIELECTRICS): glass objects refract; a path inside glass tests
 // triangles from both sides.
 template <int MODE, bool STATS, bool DIEL = false>
-__global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene sc, Sky sky, RenderArgs a, int refillBelow, int nodeMin, int leafGroupMin,
+__global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(rtamd_frame_cbuffer camera /* first: see cameraArg */, FastScene sc, Sky sky, RenderArgs a, int refillBelow, int nodeMin, int leafGroupMin,
                                                        int stackLimit, unsigned long long* stats) {
     unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define RT_STAT2(slot, cond) do { } while (0)
@@ -667,12 +667,14 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(FastScene s
             }
             if (!haveRay && pixelActive) {
                 // start the next sample of this pixel
-                float jx = a.cb.PixelOffset[0], jy = a.cb.PixelOffset[1];
+                (void)camera;
+                const CameraArgPtr camPtr = cameraArg();
+                float jx = camPtr->PixelOffset[0], jy = camPtr->PixelOffset[1];
                 if (MODE == kModePt) {
                     key = rngKey(a.seedHi, a.seedLo, (uint32_t)((size_t)py * a.width + px), (uint32_t)(a.sampleOffset + sample));
                     if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
                 }
-                const Ray cam = cameraRay(a.cb, pixelToNdc(px, jx, a.width), pixelToNdc(py, jy, a.height));
+                const Ray cam = cameraRayArg(camPtr, pixelToNdc(px, jx, a.width), pixelToNdc(py, jy, a.height), 0.0f);
                 nextO = cam.origin; nextD = cam.direction;
                 energy = v3(1, 1, 1); L = v3(0, 0, 0); bounce = 0;
                 insideGlass = false;
@@ -832,7 +834,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         // identity of the un-jittered primary hit: a separate, uncounted pass
         RenderArgs ids = a;
         ids.outRgba = nullptr; ids.accum = nullptr; ids.spp = 1;
-        hipLaunchKernelGGL((kFast<kModePrimary, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, ids, primaryCfg.refillBelow, primaryCfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((kFast<kModePrimary, false>), dim3(grid), dim3(kBlockThreads), 0, stream, ids.cb, sc, sky, ids, primaryCfg.refillBelow, primaryCfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         // the work-queue head and ray counter are shared: reset them between the passes
         if ((e = hipMemsetAsync(a.rayCount, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
@@ -841,7 +843,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         // diagnostic build: per-phase execution counts and active lanes, printed to stderr
         if ((e = fs.stats.ensure(16)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(fs.stats.p, 0, 16 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL((kFast<kModePt, true>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, fs.stats.p);
+        hipLaunchKernelGGL((kFast<kModePt, true>), dim3(grid), dim3(kBlockThreads), 0, stream, a.cb, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, fs.stats.p);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         unsigned long long h[16];
         if ((e = hipMemcpyAsync(h, fs.stats.p, sizeof(h), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
@@ -853,11 +855,11 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
         return hipSuccess;
     }
     if (a.mode == RTAMD_MODE_PT && (a.flags & RTAMD_FLAG_DIELECTRICS))
-        hipLaunchKernelGGL((kFast<kModePt, false, true>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((kFast<kModePt, false, true>), dim3(grid), dim3(kBlockThreads), 0, stream, a.cb, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
     else if (a.mode == RTAMD_MODE_PT)
-        hipLaunchKernelGGL((kFast<kModePt, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((kFast<kModePt, false>), dim3(grid), dim3(kBlockThreads), 0, stream, a.cb, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
     else
-        hipLaunchKernelGGL((kFast<kModeRef, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((kFast<kModeRef, false>), dim3(grid), dim3(kBlockThreads), 0, stream, a.cb, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 

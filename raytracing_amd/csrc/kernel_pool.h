@@ -372,15 +372,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(rtamd_frame
                                 const uint32_t pix = (uint32_t)y * (uint32_t)a.width + (uint32_t)x;
                                 if (!((a.redoMask[pix >> 5] >> (pix & 31u)) & 1u)) {
                                     const uint32_t key = rngKey(a.seedHi, a.seedLo, pix, (uint32_t)(a.sampleOffset + b.sampleBase + smp));
-                                    // The camera block (two matrices, the pixel offset: 36 scalars) is needed only here, once per
-                                    // new path.  Read as an ordinary argument it would sit in scalar registers for the whole kernel
-                                    // (and, there being too few, shuttle through lanes of a vector register at every use): it is the
-                                    // kernel's first argument and is read here from the argument block itself, through a pointer
-                                    // the compiler cannot see through.
+                                    // (the camera block is read here, from the argument block: see cameraArg)
                                     (void)camera;
-                                    typedef const __attribute__((address_space(4))) rtamd_frame_cbuffer* CameraPtr;
-                                    CameraPtr camPtr = (CameraPtr)__builtin_amdgcn_kernarg_segment_ptr();
-                                    asm volatile("" : "+s"(camPtr));
+                                    const CameraArgPtr camPtr = cameraArg();
                                     float jx = camPtr->PixelOffset[0], jy = camPtr->PixelOffset[1];
                                     if (!(a.flags & RTAMD_FLAG_NO_JITTER)) { jx = rngDraw(key, 0u); jy = rngDraw(key, 1u); }
                                     // (The frame's size as floats, the zero of the shader's float4(uv, 0, 1) and the 1 of a new path's
@@ -391,15 +385,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(rtamd_frame
                                     float zeroOpaque = 0.0f;
                                     asm volatile("" : "+s"(wOpaque), "+s"(hOpaque));
                                     asm volatile("" : "+v"(zeroOpaque));
-                                    // (cameraRay of kernel_common.h, operation for operation, on scalars read from the argument block)
-                                    const float ndcU = pixelToNdc(x, jx, wOpaque), ndcV = pixelToNdc(y, jy, hOpaque);
-                                    V3 cd = v3(((camPtr->CameraInverseProjection[0] * ndcU + camPtr->CameraInverseProjection[4] * ndcV) + camPtr->CameraInverseProjection[8] * zeroOpaque) + camPtr->CameraInverseProjection[12],
-                                               ((camPtr->CameraInverseProjection[1] * ndcU + camPtr->CameraInverseProjection[5] * ndcV) + camPtr->CameraInverseProjection[9] * zeroOpaque) + camPtr->CameraInverseProjection[13],
-                                               ((camPtr->CameraInverseProjection[2] * ndcU + camPtr->CameraInverseProjection[6] * ndcV) + camPtr->CameraInverseProjection[10] * zeroOpaque) + camPtr->CameraInverseProjection[14]);
-                                    cd = v3((camPtr->CameraToWorld[0] * cd.x + camPtr->CameraToWorld[4] * cd.y) + camPtr->CameraToWorld[8] * cd.z,
-                                            (camPtr->CameraToWorld[1] * cd.x + camPtr->CameraToWorld[5] * cd.y) + camPtr->CameraToWorld[9] * cd.z,
-                                            (camPtr->CameraToWorld[2] * cd.x + camPtr->CameraToWorld[6] * cd.y) + camPtr->CameraToWorld[10] * cd.z);
-                                    const Ray r = makeRay(v3(camPtr->CameraToWorld[12], camPtr->CameraToWorld[13], camPtr->CameraToWorld[14]), normalize(cd));
+                                    const Ray r = cameraRayArg(camPtr, pixelToNdc(x, jx, wOpaque), pixelToNdc(y, jy, hOpaque), zeroOpaque);
                                     if (rayDegenerate(r)) poolHandOverPath(a, b, (uint32_t)p, pix);
                                     else {
                                         recStore(RT_HOT(0, rs), make_float4(r.origin.x, r.origin.y, r.origin.z, r.direction.x));
@@ -689,7 +675,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         long long blocksNeeded = ((long long)fs.hSuper.size() * 1024 + kBlockThreads - 1) / kBlockThreads;
         int grid = numCU * cfg.blocksPerCU;
         if (blocksNeeded < grid) grid = (int)blocksNeeded;
-        hipLaunchKernelGGL((kFast<kModePrimary, false>), dim3(grid), dim3(kBlockThreads), 0, stream, sc, sky, ids, primaryCfg.refillBelow, primaryCfg.nodeMin,
+        hipLaunchKernelGGL((kFast<kModePrimary, false>), dim3(grid), dim3(kBlockThreads), 0, stream, ids.cb, sc, sky, ids, primaryCfg.refillBelow, primaryCfg.nodeMin,
                            cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipMemsetAsync(a.rayCount, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
