@@ -39,16 +39,17 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--workloads", default="spheres,mesh")
     ap.add_argument("--mesh-tris", type=int, default=200_000, help="triangle count of the mesh workload (1 000 000: the large-scene variant of the pool kernel)")
+    ap.add_argument("--seed", type=int, default=2025, help="seed of the random cameras (and offset of the soups' seeds)")
     args = ap.parse_args()
     w, h = args.width, args.height
     rt = backend.RayTracingPass(0)
-    rs = np.random.RandomState(2025)
+    rs = np.random.RandomState(args.seed)
     bad_total = 0
     for wl in args.workloads.split(","):
         if wl == "soup":
             # a new random scene per "camera"
             for ci in range(args.cameras):
-                buf, frame, sky = scenes.random_soup(w, h, seed=ci)
+                buf, frame, sky = scenes.random_soup(w, h, seed=ci + (args.seed - 2025))
                 rt.SetScene(buf)
                 rt.SetSkyBox(sky)
                 bad_total += compare(rt, wl, ci, frame, w, h, args.spp)
