@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
+#include <stdexcept>
 
 #include "host_internal.h"
 
@@ -431,20 +433,29 @@ extern "C" {
 int rtamd_host_image_load(const char* path, int32_t flip_y, float** out_rgba, int32_t* out_w, int32_t* out_h) {
     if (!path || !out_rgba || !out_w || !out_h) { setLastError("NULL argument"); return -1; }
     *out_rgba = nullptr; *out_w = *out_h = 0;
-    std::vector<uint8_t> file;
-    if (!readFile(path, file)) return -1;
-    std::vector<float> rgba;
-    int W = 0, H = 0;
-    bool ok;
-    if (file.size() >= 4 && file[0] == 0x76 && file[1] == 0x2f && file[2] == 0x31 && file[3] == 0x01) ok = loadExr(file, flip_y != 0, rgba, W, H);
-    else if (file.size() >= 2 && file[0] == '#' && file[1] == '?') ok = loadHdr(file, flip_y != 0, rgba, W, H);
-    else { setLastError("unknown image format (expected OpenEXR or Radiance RGBE)"); ok = false; }
-    if (!ok) return -1;
-    float* p = (float*)std::malloc(rgba.size() * sizeof(float));
-    if (!p) { setLastError("out of memory"); return -1; }
-    std::memcpy(p, rgba.data(), rgba.size() * sizeof(float));
-    *out_rgba = p; *out_w = W; *out_h = H;
-    return 0;
+    // (a damaged file is an error code, whatever sizes it claims)
+    try {
+        std::vector<uint8_t> file;
+        if (!readFile(path, file)) return -1;
+        std::vector<float> rgba;
+        int W = 0, H = 0;
+        bool ok;
+        if (file.size() >= 4 && file[0] == 0x76 && file[1] == 0x2f && file[2] == 0x31 && file[3] == 0x01) ok = loadExr(file, flip_y != 0, rgba, W, H);
+        else if (file.size() >= 2 && file[0] == '#' && file[1] == '?') ok = loadHdr(file, flip_y != 0, rgba, W, H);
+        else { setLastError("unknown image format (expected OpenEXR or Radiance RGBE)"); ok = false; }
+        if (!ok) return -1;
+        float* p = (float*)std::malloc(rgba.size() * sizeof(float));
+        if (!p) { setLastError("out of memory"); return -1; }
+        std::memcpy(p, rgba.data(), rgba.size() * sizeof(float));
+        *out_rgba = p; *out_w = W; *out_h = H;
+        return 0;
+    } catch (const std::bad_alloc&) {
+        setLastError("out of memory reading an image");
+        return -1;
+    } catch (const std::exception& ex) {
+        setLastError(std::string("image file: ") + ex.what());
+        return -1;
+    }
 }
 
 void rtamd_host_image_free(float* rgba) { std::free(rgba); }

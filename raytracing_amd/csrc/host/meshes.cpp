@@ -11,6 +11,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
+#include <stdexcept>
+#include <vector>
 #include <string>
 
 #include "host_internal.h"
@@ -32,9 +35,11 @@ int emit(const MeshBuf& m, rtamd_host_mesh* out) {
         rtamd_host_mesh_free(out);
         return RTAMD_ERR_OUT_OF_MEMORY;
     }
-    std::memcpy(out->positions, m.pos.data(), sizeof(float) * 3 * nv);
-    std::memcpy(out->normals, m.nrm.data(), sizeof(float) * 3 * nv);
-    std::memcpy(out->indices, m.idx.data(), sizeof(int32_t) * 3 * nt);
+    if (nv) {
+        std::memcpy(out->positions, m.pos.data(), sizeof(float) * 3 * nv);
+        std::memcpy(out->normals, m.nrm.data(), sizeof(float) * 3 * nv);
+    }
+    if (nt) std::memcpy(out->indices, m.idx.data(), sizeof(int32_t) * 3 * nt);
     out->n_vertices = (int32_t)nv;
     out->n_triangles = (int32_t)nt;
     return RTAMD_OK;
@@ -149,63 +154,80 @@ int rtamd_host_mesh_cube(rtamd_host_mesh* out) {
     return emit(m, out);
 }
 
-int rtamd_host_mesh_load_dae(const char* path, rtamd_host_mesh* out) {
-    if (!path || !out) return RTAMD_ERR_INVALID_ARG;
-    std::memset(out, 0, sizeof(*out));
+}  // extern "C"
+
+namespace {
+
+// "#id" -> "id" (a source reference); anything else as it is
+std::string afterHash(const std::string& ref) { return (!ref.empty() && ref[0] == '#') ? ref.substr(1) : ref; }
+
+// numbers between two positions of the text (strtof / strtol stop at the first character that is not part of one)
+template <typename T, typename Parse>
+void parseNumbers(const std::string& x, size_t b, size_t e, std::vector<T>& out, Parse parse) {
+    if (b == std::string::npos || e == std::string::npos || b >= e || e > x.size()) return;
+    const std::string piece = x.substr(b, e - b);      // (a copy with its own terminator: parsing cannot run past `e`)
+    const char* c = piece.c_str();
+    for (;;) {
+        char* next = nullptr;
+        const T v = parse(c, &next);
+        if (next == c) break;
+        out.push_back(v);
+        c = next;
+    }
+}
+
+int loadDae(const char* path, rtamd_host_mesh* out) {
+    const size_t npos = std::string::npos;
     std::string x = readFile(path);
     if (x.empty()) { setLastError(std::string("cannot read ") + path); return RTAMD_ERR_INVALID_ARG; }
-    bool zUp = x.find("<up_axis>Z_UP</up_axis>") != std::string::npos;
+    bool zUp = x.find("<up_axis>Z_UP</up_axis>") != npos;
     size_t mesh = x.find("<mesh>");
-    size_t meshEnd = x.find("</mesh>", mesh);
-    if (mesh == std::string::npos || meshEnd == std::string::npos) { setLastError("no <mesh>"); return RTAMD_ERR_INVALID_ARG; }
+    size_t meshEnd = mesh == npos ? npos : x.find("</mesh>", mesh);
+    if (mesh == npos || meshEnd == npos) { setLastError("no <mesh>"); return RTAMD_ERR_INVALID_ARG; }
 
     // sources: id -> floats
     std::map<std::string, std::vector<float>> sources;
     size_t p = mesh;
-    while ((p = x.find("<source ", p)) != std::string::npos && p < meshEnd) {
+    while ((p = x.find("<source ", p)) != npos && p < meshEnd) {
         size_t te = x.find('>', p);
+        size_t se = te == npos ? npos : x.find("</source>", te);
+        if (se == npos || se > meshEnd) { setLastError("unterminated <source>"); return RTAMD_ERR_INVALID_ARG; }
         std::string id = attr(x.substr(p, te - p), "id");
         size_t fa = x.find("<float_array", te);
-        size_t se = x.find("</source>", te);
-        if (fa != std::string::npos && fa < se) {
-            size_t b = x.find('>', fa) + 1, e = x.find("</float_array>", b);
-            std::vector<float>& v = sources[id];
-            const char* c = x.c_str() + b;
-            const char* end = x.c_str() + e;
-            while (c < end) {
-                char* next;
-                float f = std::strtof(c, &next);
-                if (next == c) break;
-                v.push_back(f);
-                c = next;
-            }
+        if (fa != npos && fa < se) {
+            size_t open = x.find('>', fa), e = x.find("</float_array>", fa);
+            if (open == npos || e == npos || open > e || e > se) { setLastError("unterminated <float_array>"); return RTAMD_ERR_INVALID_ARG; }
+            parseNumbers<float>(x, open + 1, e, sources[id], [](const char* c, char** next) { return std::strtof(c, next); });
         }
         p = se;
     }
     // <vertices id=..><input semantic="POSITION" source="#..."/>
     std::map<std::string, std::string> vertexPos;
     p = mesh;
-    while ((p = x.find("<vertices ", p)) != std::string::npos && p < meshEnd) {
+    while ((p = x.find("<vertices ", p)) != npos && p < meshEnd) {
         size_t te = x.find('>', p);
+        size_t in = te == npos ? npos : x.find("<input", te);
+        size_t ie = in == npos ? npos : x.find('>', in);
+        if (ie == npos || ie > meshEnd) { setLastError("unterminated <vertices>"); return RTAMD_ERR_INVALID_ARG; }
         std::string id = attr(x.substr(p, te - p), "id");
-        size_t in = x.find("<input", te);
-        size_t ie = x.find('>', in);
         std::string tag = x.substr(in, ie - in);
-        if (attr(tag, "semantic") == "POSITION") vertexPos[id] = attr(tag, "source").substr(1);
+        if (attr(tag, "semantic") == "POSITION") vertexPos[id] = afterHash(attr(tag, "source"));
         p = ie;
     }
     size_t tr = x.find("<triangles", mesh);
-    if (tr == std::string::npos || tr > meshEnd) { setLastError("no <triangles>"); return RTAMD_ERR_INVALID_ARG; }
+    if (tr == npos || tr > meshEnd) { setLastError("no <triangles>"); return RTAMD_ERR_INVALID_ARG; }
     size_t trEnd = x.find("</triangles>", tr);
+    if (trEnd == npos || trEnd > meshEnd) { setLastError("unterminated <triangles>"); return RTAMD_ERR_INVALID_ARG; }
     int stride = 0, offV = -1, offN = -1;
     std::string posSrc, nrmSrc;
     p = tr;
-    while ((p = x.find("<input", p)) != std::string::npos && p < trEnd) {
+    while ((p = x.find("<input", p)) != npos && p < trEnd) {
         size_t ie = x.find('>', p);
+        if (ie == npos || ie > trEnd) { setLastError("unterminated <input>"); return RTAMD_ERR_INVALID_ARG; }
         std::string tag = x.substr(p, ie - p);
         int off = std::atoi(attr(tag, "offset").c_str());
-        std::string sem = attr(tag, "semantic"), src = attr(tag, "source");
-        if (!src.empty()) src = src.substr(1);
+        if (off < 0 || off > 63) { setLastError("<input> offset out of range"); return RTAMD_ERR_INVALID_ARG; }
+        std::string sem = attr(tag, "semantic"), src = afterHash(attr(tag, "source"));
         if (sem == "VERTEX") { offV = off; posSrc = vertexPos.count(src) ? vertexPos[src] : src; }
         if (sem == "NORMAL") { offN = off; nrmSrc = src; }
         if (off + 1 > stride) stride = off + 1;
@@ -215,31 +237,21 @@ int rtamd_host_mesh_load_dae(const char* path, rtamd_host_mesh* out) {
     const std::vector<float>& P = sources[posSrc];
     const std::vector<float>* N = (offN >= 0 && sources.count(nrmSrc)) ? &sources[nrmSrc] : nullptr;
     size_t pb = x.find("<p>", tr);
-    if (pb == std::string::npos || pb > trEnd) { setLastError("no <p>"); return RTAMD_ERR_INVALID_ARG; }
-    pb += 3;
-    size_t pe = x.find("</p>", pb);
-    std::vector<int> raw;
-    {
-        const char* c = x.c_str() + pb;
-        const char* end = x.c_str() + pe;
-        while (c < end) {
-            char* next;
-            long v = std::strtol(c, &next, 10);
-            if (next == c) break;
-            raw.push_back((int)v);
-            c = next;
-        }
-    }
+    size_t pe = pb == npos ? npos : x.find("</p>", pb);
+    if (pb == npos || pe == npos || pe > trEnd) { setLastError("no <p>"); return RTAMD_ERR_INVALID_ARG; }
+    std::vector<long> raw;
+    parseNumbers<long>(x, pb + 3, pe, raw, [](const char* c, char** next) { return std::strtol(c, next, 10); });
     MeshBuf m;
     std::map<std::pair<int, int>, int> weld;   // (position index, normal index) -> vertex, first-seen order
-    size_t corners = raw.size() / stride;
+    size_t corners = raw.size() / (size_t)stride;
     for (size_t c = 0; c < corners; c++) {
-        int vi = raw[c * stride + offV];
-        int ni = N ? raw[c * stride + offN] : -1;
-        if (vi < 0 || (size_t)vi * 3 + 2 >= P.size() || (N && (ni < 0 || (size_t)ni * 3 + 2 >= N->size()))) {
+        const long vl = raw[c * stride + offV];
+        const long nl = N ? raw[c * stride + offN] : -1;
+        if (vl < 0 || (unsigned long)vl >= P.size() / 3 || (N && (nl < 0 || (unsigned long)nl >= N->size() / 3))) {
             setLastError("index out of range in <p>");
             return RTAMD_ERR_BAD_INDEX;
         }
+        const int vi = (int)vl, ni = (int)nl;
         auto key = std::make_pair(vi, ni);
         auto it = weld.find(key);
         int id;
@@ -261,7 +273,27 @@ int rtamd_host_mesh_load_dae(const char* path, rtamd_host_mesh* out) {
         m.idx.push_back(id);
     }
     m.idx.resize(m.idx.size() / 3 * 3);
+    if (m.idx.empty()) { setLastError("no triangle in <p>"); return RTAMD_ERR_INVALID_ARG; }
     return emit(m, out);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtamd_host_mesh_load_dae(const char* path, rtamd_host_mesh* out) {
+    if (!path || !out) return RTAMD_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof(*out));
+    // (a damaged file is an error code, whatever it makes the standard library throw)
+    try {
+        return loadDae(path, out);
+    } catch (const std::bad_alloc&) {
+        setLastError("out of memory reading a COLLADA file");
+        return RTAMD_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception& ex) {
+        setLastError(std::string("COLLADA file: ") + ex.what());
+        return RTAMD_ERR_INVALID_ARG;
+    }
 }
 
 int rtamd_host_mesh_subdivide(const rtamd_host_mesh* in, int32_t rounds, rtamd_host_mesh* out) {

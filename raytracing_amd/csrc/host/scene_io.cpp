@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <new>
+#include <vector>
 
 #include "host_internal.h"
 
@@ -109,20 +111,43 @@ int rtamd_host_scene_load(rtamd_host_scene* s, const char* path) {
     bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, kMagic, 8) == 0 && std::fread(hdr, 4, 8, f) == 8;
     for (int i = 0; ok && i < 6; i++) ok = hdr[i] >= 0 && hdr[i] < (1 << 30);
     if (ok) {
-        auto get = [&](void* p, size_t sz, size_t n) { if (ok && n) ok = std::fread(p, sz, n, f) == n; };
-        s->tlas.resize(hdr[0]); s->blasNodes.resize(hdr[1]); s->vertices.resize(hdr[2]); s->triangles.resize(hdr[3]);
-        s->blasOffsets.resize(hdr[4]); s->vtxOffsets.resize(hdr[4]); s->triOffsets.resize(hdr[4]);
-        s->objects.resize(hdr[5]); s->nBlas = hdr[4]; s->branchCount = hdr[6];
-        get(s->tlas.data(), sizeof(rtamd_node), hdr[0]);
-        get(s->blasOffsets.data(), 4, hdr[4]);
-        get(s->blasNodes.data(), sizeof(rtamd_node), hdr[1]);
-        get(s->vtxOffsets.data(), 4, hdr[4]);
-        get(s->vertices.data(), sizeof(rtamd_vertex), hdr[2]);
-        get(s->triOffsets.data(), 4, hdr[4]);
-        get(s->triangles.data(), sizeof(rtamd_int3), hdr[3]);
-        get(s->objects.data(), sizeof(rtamd_object_property), hdr[5]);
+        // the counts must account for the rest of the file exactly, before anything is sized by them
+        const uint64_t need = (uint64_t)hdr[0] * sizeof(rtamd_node) + (uint64_t)hdr[1] * sizeof(rtamd_node) + (uint64_t)hdr[2] * sizeof(rtamd_vertex) +
+                              (uint64_t)hdr[3] * sizeof(rtamd_int3) + (uint64_t)hdr[4] * 12u + (uint64_t)hdr[5] * sizeof(rtamd_object_property);
+        ok = std::fseek(f, 0, SEEK_END) == 0;
+        const long size = ok ? std::ftell(f) : -1;
+        ok = ok && size >= 40 && (uint64_t)(size - 40) == need && std::fseek(f, 40, SEEK_SET) == 0;
+    }
+    int rc = RTAMD_OK;
+    if (ok) {
+        try {
+            // into buffers of its own first: a file that ends early leaves the scene as it was
+            std::vector<rtamd_node> tlas(hdr[0]), blasNodes(hdr[1]);
+            std::vector<rtamd_vertex> vertices(hdr[2]);
+            std::vector<rtamd_int3> triangles(hdr[3]);
+            std::vector<int32_t> blasOffsets(hdr[4]), vtxOffsets(hdr[4]), triOffsets(hdr[4]);
+            std::vector<rtamd_object_property> objects(hdr[5]);
+            auto get = [&](void* p, size_t sz, size_t n) { if (ok && n) ok = std::fread(p, sz, n, f) == n; };
+            get(tlas.data(), sizeof(rtamd_node), hdr[0]);
+            get(blasOffsets.data(), 4, hdr[4]);
+            get(blasNodes.data(), sizeof(rtamd_node), hdr[1]);
+            get(vtxOffsets.data(), 4, hdr[4]);
+            get(vertices.data(), sizeof(rtamd_vertex), hdr[2]);
+            get(triOffsets.data(), 4, hdr[4]);
+            get(triangles.data(), sizeof(rtamd_int3), hdr[3]);
+            get(objects.data(), sizeof(rtamd_object_property), hdr[5]);
+            if (ok) {
+                s->tlas.swap(tlas); s->blasNodes.swap(blasNodes); s->vertices.swap(vertices); s->triangles.swap(triangles);
+                s->blasOffsets.swap(blasOffsets); s->vtxOffsets.swap(vtxOffsets); s->triOffsets.swap(triOffsets);
+                s->objects.swap(objects); s->nBlas = hdr[4]; s->branchCount = hdr[6];
+            }
+        } catch (const std::bad_alloc&) {
+            setLastError("out of memory reading a scene file");
+            rc = RTAMD_ERR_OUT_OF_MEMORY;
+        }
     }
     std::fclose(f);
+    if (rc != RTAMD_OK) return rc;
     if (!ok) { setLastError("bad scene file"); return RTAMD_ERR_INVALID_ARG; }
     return RTAMD_OK;
 }
