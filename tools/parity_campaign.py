@@ -17,10 +17,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracing_amd import backend, scenes, types as T  # noqa: E402
 
 
-def compare(rt, wl, ci, frame, w, h, spp):
+def compare(rt, wl, ci, frame, w, h, spp, flags=0):
     kw = dict(mode=T.MODE_PT, spp=spp, max_bounces=8, seed=1000 + ci)
-    a = rt.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, **kw)
-    b = rt.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, flags=T.FLAG_REFERENCE_ORDER, **kw)
+    a = rt.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, flags=flags, **kw)
+    b = rt.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, flags=flags | T.FLAG_REFERENCE_ORDER, **kw)
     ids = int((a["ids"] != b["ids"]).any(-1).sum())
     tt = int(((a["t"] != b["t"]) & ~(np.isnan(a["t"]) & np.isnan(b["t"]))).sum())
     rgba = int(((a["rgba"] != b["rgba"]) & ~(np.isnan(a["rgba"]) & np.isnan(b["rgba"]))).any(-1).sum())
@@ -60,6 +60,10 @@ def main():
         elif wl == "mesh":
             buf, frame0, sky = scenes.mesh_scene(w, h, target_tris=args.mesh_tris)
             centre, radius = np.array([0.0, 1.0, 0.0]), 6.0
+        elif wl == "glass":
+            # the "diffuse + dielectric" mix: every third instance is tinted glass (the dielectric variant of the kernels)
+            buf, frame0, sky = scenes.instanced_scene(w, h, instances=1250, tris_per_blas=2000, glass_every=3)
+            centre, radius = np.array([0.0, 1.0, 0.0]), 40.0
         else:
             buf, frame0, sky = scenes.instanced_scene(w, h, instances=1250, tris_per_blas=2000)
             centre, radius = np.array([0.0, 1.0, 0.0]), 40.0
@@ -73,7 +77,7 @@ def main():
                 eye = centre + radius * rs.uniform(0.3, 1.2) * np.array([np.cos(ang), 0.0, np.sin(ang)]) + np.array([0, rs.uniform(0.3, 8.0), 0])
                 tgt = centre + rs.uniform(-2, 2, size=3) * np.array([1, 0.2, 1])
                 frame = scenes.look_at_camera(tuple(eye), tuple(tgt), float(rs.uniform(25, 70)), w, h)
-            bad_total += compare(rt, wl, ci, frame, w, h, args.spp)
+            bad_total += compare(rt, wl, ci, frame, w, h, args.spp, T.FLAG_DIELECTRICS if wl == "glass" else 0)
     print("total mismatches", bad_total)
     return 1 if bad_total else 0
 
