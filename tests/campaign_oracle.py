@@ -3,7 +3,7 @@
 on the GPU box's 16 host cores).  The production kernels, through the C ABI, against oracle/ on the same scenes and
 random cameras: primary ids, t, radiance and ray counts of every pixel, tolerance 0.
 
-    python tests/campaign_oracle.py [--cameras N] [--spp S] [--workloads spheres,mesh,instanced,glass,soup]
+    python tests/campaign_oracle.py [--mode pt|ref] [--cameras N] [--spp S] [--workloads spheres,mesh,instanced,glass,soup]
 
 Prints one line per frame and a total; exit status 1 if anything differs."""
 import argparse
@@ -18,12 +18,15 @@ from oracle import oracle as O  # noqa: E402
 from raytracing_amd import backend, scenes, types as T  # noqa: E402
 
 
+REF_MODE = False      # --mode ref: what the reference shader renders (primary + mirror ray) instead of the path tracer
+
+
 def compare(rt, wl, ci, buf, frame, sky, w, h, spp, flags, threads):
-    kw = dict(spp=spp, max_bounces=8, seed=3000 + ci)
+    kw = dict(spp=spp, max_bounces=8, seed=3000 + ci) if not REF_MODE else {}
     t0 = time.time()
-    g = rt.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, mode=T.MODE_PT, flags=flags, **kw)
+    g = rt.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, mode=T.MODE_REF if REF_MODE else T.MODE_PT, flags=flags, **kw)
     t1 = time.time()
-    o = O.render(buf, frame, w, h, sky=sky, mode=1, nthreads=threads, flags=flags, **kw)
+    o = O.render(buf, frame, w, h, sky=sky, mode=0 if REF_MODE else 1, nthreads=threads, flags=flags, **kw)
     t2 = time.time()
     ids = int((g["ids"] != o["ids"]).any(-1).sum())
     tt = int(((g["t"] != o["t"]) & ~(np.isnan(g["t"]) & np.isnan(o["t"]))).sum())
@@ -45,7 +48,10 @@ def main():
     ap.add_argument("--mesh-tris", type=int, default=1_000_000)
     ap.add_argument("--seed", type=int, default=99)
     ap.add_argument("--threads", type=int, default=min(os.cpu_count() or 1, 16))
+    ap.add_argument("--mode", default="pt", choices=["pt", "ref"])
     args = ap.parse_args()
+    global REF_MODE
+    REF_MODE = args.mode == "ref"
     w, h = args.width, args.height
     O.lib()
     rt = backend.RayTracingPass(0)
