@@ -606,15 +606,16 @@ struct PoolHost {
 // on the 1M-triangle scene), so a batch is as large as memory reasonably allows: 2^29 paths (2 x 8 GB of samples
 // for a frame of several batches) when that is at most an eighth of the device's memory, 2^27 at least.
 inline size_t poolMaxPaths() {
-    static size_t byMemory = 0;
-    if (!byMemory) {
-        byMemory = (size_t)1 << 27;
+    // (worked out once; contexts of several devices may ask at the same time from their own host threads)
+    static const size_t byMemory = []() -> size_t {
+        size_t paths = (size_t)1 << 27;
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) == hipSuccess)
-            while (byMemory < ((size_t)1 << 29) && 2 * (2 * byMemory) * sizeof(float4) <= totalB / 8) byMemory *= 2;
+            while (paths < ((size_t)1 << 29) && 2 * (2 * paths) * sizeof(float4) <= totalB / 8) paths *= 2;
         else
             (void)hipGetLastError();
-    }
+        return paths;
+    }();
     size_t cap = byMemory;
     if (const char* s = getenv("RTAMD_POOL_MAX_PATHS")) { long long v = atoll(s); if (v >= 1024) cap = (size_t)v; }
     if (cap > ((size_t)1 << 31)) cap = (size_t)1 << 31;       // (a path's place in its batch is a 32-bit number)
