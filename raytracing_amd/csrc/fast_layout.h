@@ -16,7 +16,7 @@ struct alignas(128) WNode {
 };
 struct alignas(64) FTri { float4 a, b, c, d; };
 struct alignas(16) FNrm { float4 a, b, c; };                            // n0.xyz n1.x | n1.yz n2.xy | n2.z
-struct alignas(32) FInst { float4 r0, r1, r2; float4 b0; float bhy, bhz; int32_t root, object; float4 pad; };   // b0 = lo.xyz, hi.x
+struct alignas(32) FInst { float4 r0, r1, r2; float4 bxy; float blz, bhz; int32_t root, object; float4 pad; };   // TLAS slot box as (lo, hi) pairs: bxy = lo.x, hi.x, lo.y, hi.y
 struct alignas(32) FShade { float4 r0, r1, r2; float4 albedo, specular, emission; };
 
 // child / stack words: >= 0 node index; < 0: ~payload, payload bit 30 set = instance rank,

@@ -138,6 +138,17 @@ struct FastSceneHost {
         levelStart.push_back((int32_t)order.size());
     }
 
+    // A two-triangle leaf is one 128-byte line holding the two records component by component — 16 pairs
+    // (triangle 0, triangle 1): lo.xyz, hi.xyz, v0.xyz, e1.xyz, e2.xyz, rank — so that the kernel tests both
+    // slot boxes and both triangles with two-wide instructions.  `pair` points at the two records as gathered.
+    static void interleaveLeaf(FTri* pair) {
+        static const int kComponent[16] = {0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 6};
+        float in[2][16], out[32];
+        std::memcpy(in, pair, sizeof(in));
+        for (int j = 0; j < 16; j++) { out[2 * j] = in[0][kComponent[j]]; out[2 * j + 1] = in[1][kComponent[j]]; }
+        std::memcpy(pair, out, sizeof(out));
+    }
+
     // Re-build every BLAS.  Inputs were validated by the caller (indices in range, every
     // node reachable at most once).  From the caller's tree come, per triangle, its leaf-slot
     // box and its rank in the reference's visiting order (children pushed 0..3, popped last
@@ -225,6 +236,7 @@ struct FastSceneHost {
                     newStart[i] = (int32_t)(ft.size() - triBases[b]);
                     for (int k = 0; k < cnt; k++) ft.push_back(ranked[tree.order[i + (size_t)k]]);
                     if (ft.size() & 1u) ft.push_back(blank);
+                    interleaveLeaf(&ft[ft.size() - 2]);
                     i += (size_t)cnt;
                 }
                 for (WideTree::Node& nd : tree.nodes)

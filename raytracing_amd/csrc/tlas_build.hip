@@ -40,9 +40,9 @@ __device__ __forceinline__ float fromOrderedBits(uint32_t u) {
 struct Box3 { float lx, ly, lz, hx, hy, hz; };
 
 __device__ __forceinline__ Box3 instBox(const FInst* inst, uint32_t r) {
-    const float4 b0 = inst[r].b0;
+    const float4 bxy = inst[r].bxy;
     Box3 b;
-    b.lx = b0.x; b.ly = b0.y; b.lz = b0.z; b.hx = b0.w; b.hy = inst[r].bhy; b.hz = inst[r].bhz;
+    b.lx = bxy.x; b.hx = bxy.y; b.ly = bxy.z; b.hy = bxy.w; b.lz = inst[r].blz; b.hz = inst[r].bhz;
     return b;
 }
 // a centroid coordinate; boxes that are not finite sort to the origin (their own box still decides hits)
@@ -336,8 +336,8 @@ __global__ __launch_bounds__(kThreads) void kTlasPack(const rtamd_node* tlas, co
     fi.r0 = make_float4(m[0], m[4], m[8], m[12]);
     fi.r1 = make_float4(m[1], m[5], m[9], m[13]);
     fi.r2 = make_float4(m[2], m[6], m[10], m[14]);
-    fi.b0 = make_float4(nd.Lx[i], nd.Ly[i], nd.Lz[i], nd.Hx[i]);
-    fi.bhy = nd.Hy[i]; fi.bhz = nd.Hz[i];
+    fi.bxy = make_float4(nd.Lx[i], nd.Hx[i], nd.Ly[i], nd.Hy[i]);
+    fi.blz = nd.Lz[i]; fi.bhz = nd.Hz[i];
     fi.root = blasRoot[o.BLASIndex]; fi.object = d;
     fi.pad = make_float4(0.f, 0.f, 0.f, 0.f);
     inst[r] = fi;
