@@ -32,8 +32,9 @@
 // Layout (arrays 128-byte aligned in HBM; a lane's node is exactly one 128-byte line):
 //   WNode  128 B  lx,hx,ly,hy,lz,hz (float4 = the four children), child[4], pad;
 //                 the TLAS in front (breadth first, one slot per object reserved), then the BLAS nodes level by level
-//   FTri    64 B  (lo.xyz,hi.x)(hi.yz,rank,v0.x)(v0.yz,e1.xy)(e1.z,e2.xyz) — leaf order of the new tree;
-//                 rank = position in the reference's visiting order
+//   FTri    64 B  per triangle: leaf-slot box lo.xyz, hi.xyz, v0, e1, e2, rank (= position in the reference's visiting
+//                 order); stored in leaf order of the new tree, two records to a 128-byte line, the pair interleaved
+//                 component by component (interleaveLeaf)
 //   FNrm    48 B  n0,n1,n2, indexed by rank                  — read once per closest hit
 //   FInst   96 B  three rows of WorldToLocal, the instance's TLAS slot box, BLAS root, original object index
 //   FShade  96 B  three rows of LocalToWorld, albedo, specular, emission
@@ -56,10 +57,10 @@ namespace rt {
 #ifndef RT_LEAF_TRIS
 #define RT_LEAF_TRIS 2
 #endif
-// Triangles per leaf of the rebuilt BLAS trees (1..4).  Two: a leaf is one 128-byte line, and fewer slot boxes
-// and triangles are tested per visit than with the reference's four (measured against 4 / 3 / 1 per leaf:
-// +5 % on the 1M-triangle scene, +2 % on the spheres, +8 % on the 50M-instanced-triangle scene).
+// Triangles per leaf of the rebuilt BLAS trees (2 or 4; the kernels test them in pairs).  Two: a leaf is one
+// 128-byte line, and fewer slot boxes and triangles are tested per visit than with the reference's four.
 constexpr int kLeafTris = RT_LEAF_TRIS;
+static_assert(kLeafTris == 2 || kLeafTris == 4, "leaves hold whole pairs of triangles");
 
 struct FastSceneHost {
     DBuf<WNode> nodes;
@@ -220,8 +221,9 @@ struct FastSceneHost {
             buildWideTree(boxes.data(), (int)boxes.size(), kLeafTris, tree);
             if (tree.depth > maxDepth) maxDepth = tree.depth;
             triBases[b] = (uint32_t)ft.size();
-            if (kLeafTris == 2) {
-                // every leaf starts a 128-byte line (two 64-byte records): a one-triangle leaf is followed by a blank record
+            {
+                // every leaf starts a 128-byte line and is a whole number of lines (two 64-byte records each, the pair
+                // interleaved): an odd leaf ends with a blank record
                 std::vector<int32_t> leafAt(boxes.size() + 1, -1);      // first item of a leaf -> its number of items
                 for (const WideTree::Node& nd : tree.nodes)
                     for (int s4 = 0; s4 < 4; s4++)
@@ -230,13 +232,13 @@ struct FastSceneHost {
                 FTri blank;
                 blank.a = make_float4(RT_INF, RT_INF, RT_INF, RT_INF); blank.b = make_float4(RT_INF, RT_INF, 0.f, 0.f);
                 blank.c = make_float4(0.f, 0.f, 0.f, 0.f); blank.d = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((triBases[b] & 1u) != 0u) { ft.push_back(blank); triBases[b]++; }
                 for (size_t i = 0; i < boxes.size();) {
                     const int cnt = leafAt[i] > 0 ? leafAt[i] : 1;
                     newStart[i] = (int32_t)(ft.size() - triBases[b]);
+                    const size_t first = ft.size();
                     for (int k = 0; k < cnt; k++) ft.push_back(ranked[tree.order[i + (size_t)k]]);
                     if (ft.size() & 1u) ft.push_back(blank);
-                    interleaveLeaf(&ft[ft.size() - 2]);
+                    for (size_t at = first; at < ft.size(); at += 2) interleaveLeaf(&ft[at]);
                     i += (size_t)cnt;
                 }
                 for (WideTree::Node& nd : tree.nodes)
@@ -245,8 +247,6 @@ struct FastSceneHost {
                             const uint32_t code = (uint32_t)~nd.child[s4];
                             nd.child[s4] = ~(int32_t)(((uint32_t)newStart[code >> 3] << 3) | (code & 7u));
                         }
-            } else {
-                for (int32_t it : tree.order) ft.push_back(ranked[it]);
             }
             if (ft.size() >= (1u << 28)) { err = "too many triangles for the leaf encoding"; return hipSuccess; }
         }

@@ -656,9 +656,9 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         // measured optima of the three benchmark scenes: shading is cheap here (full waves), so
         // lanes are refilled earlier than in kFast; small scenes (same criterion as kFast's) walk on with few lanes
         const bool allHot = fs.nBlasNodes + (size_t)fs.nTlasNodes <= (size_t)kPoolHotNodes;
-        if (cfg.refillBelow == 0) cfg.refillBelow = 40;
+        if (cfg.refillBelow == 0) cfg.refillBelow = allHot ? 40 : 44;
         if (cfg.nodeMin == 0) {
-            cfg.nodeMin = allHot ? 12 : 16;
+            cfg.nodeMin = allHot ? 12 : 24;
             // a frame of one or two samples per pixel is over before the waves fall out of step: there the shorter
             // chain of steps counts for more than full node steps (1M-triangle scene, 1 spp: 2.47 -> 2.34 ms)
             const unsigned long long paths = (unsigned long long)fs.hSuper.size() * 1024ull * (unsigned long long)a.spp;
