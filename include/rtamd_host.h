@@ -1,20 +1,16 @@
 /*
- * rtamd_host.h — C ABI of the host-side scene producers (CPU only, no GPU calls).
+ * rtamd_host.h — C ABI of the host-side helpers (CPU only, no GPU calls): librtamd_host.so.
  *
- * These functions stand in for the C# host code that feeds the compute path of
- * houshuo/RayTracing when Unity is not available: the 4-wide BVH builder, the
- * edit-time BLAS bake, the per-frame acceleration-structure system that
- * flattens everything into the eight buffers of rtamd_scene_upload, Unity's
- * camera matrices, and mesh sources (generators, COLLADA, subdivision).
- * In a Unity build the project's own C# code produces the same buffers and this
- * library is not needed.
+ * What a caller without Unity needs around the compute path of houshuo/RayTracing: mesh
+ * sources (generators, COLLADA, subdivision), Unity's camera matrices, a 4-wide SAH tree
+ * writer in the reference's node format, the flattened scene (the eight buffers of
+ * rtamd_scene_upload) as a container and a file, and HDR image codecs for the sky and the
+ * framebuffer.  In a Unity build the project's own C# code produces the same buffers and
+ * this library is not needed.
  *
- * Reference code restated (paths relative to the reference checkout):
- *   Assets/Script/BVH/BoundingVolumeHierarchyBuilder.cs      (builder, Refit)
- *   Assets/Script/BVH/Base/Math/{Aabb,FourTransposedAabbs,Math}.cs
- *   Assets/Editor/RayTracing/Authoring/RayTraceableBaker.cs:75-149
- *   Assets/Script/RayTracing/System/BuildAccelerateStructureSystem.cs:41-163,202-300
- *   Assets/Script/RayTracing/Component/TopLevelAccelerateStructure.cs
+ * The reference's own producers restated (its median-split BVH builder, the edit-time BLAS
+ * bake and the per-frame flattening system) are test and fixture infrastructure and live in a
+ * library of their own: tests/producers/rtamd_testhost.h, librtamd_testhost.so.
  */
 #ifndef RTAMD_HOST_H
 #define RTAMD_HOST_H
@@ -31,60 +27,19 @@ typedef struct rtamd_aabb { float Min[3]; float Max[3]; } rtamd_aabb;
 /* BoundingVolumeHierarchy.PointAndIndex (BoundingVolumeHierarchyBuilder.cs:87-91). */
 typedef struct rtamd_point_and_index { float Position[3]; int32_t Index; } rtamd_point_and_index;
 
-/* BoundingVolumeHierarchy.Build (BoundingVolumeHierarchyBuilder.cs:529-558), median
- * split (useSah = false, the only mode any caller uses).  `points` is permuted in
- * place, as in the reference.  `nodes` must hold n + 64 entries
- * (RayTraceableBaker.cs:129).  Returns 0 or a negative rtamd status. */
-int rtamd_host_bvh_build(rtamd_point_and_index* points, const rtamd_aabb* aabbs, int32_t n,
-                         rtamd_node* nodes, int32_t nodes_capacity, int32_t* node_count);
-
-/* BoundingVolumeHierarchy.ScheduleBuildJobs (:482-527) run to completion:
- * BuildFirstNLevelsJob, every BuildBranchesJob, FinalizeTreeJob.  This is the
- * TLAS build path (TopLevelAccelerateStructure.cs:64-68).  `nodes` must hold
- * n + 64 entries; entries the build does not reach are left zeroed.
- * branch_count receives the number of branches. */
-int rtamd_host_bvh_build_jobs(rtamd_point_and_index* points, const rtamd_aabb* aabbs, int32_t n,
-                              rtamd_node* nodes, int32_t nodes_capacity, int32_t* branch_count);
-
-/* A better tree over the same primitives, in the same node format: binned
- * surface-area-heuristic splits (what the reference's unused SAH path, :166-260,
- * aims at).  Interchangeable with rtamd_host_bvh_build for any consumer. */
+/* A 4-wide tree over primitive boxes in the reference's node format
+ * (BoundingVolumeHierarchyBuilder.cs:31-74): binned surface-area-heuristic splits (what the
+ * reference's unused SAH path, :166-260, aims at).  `nodes` must hold n + 64 entries. */
 int rtamd_host_bvh_build_sah(const rtamd_aabb* aabbs, int32_t n,
                              rtamd_node* nodes, int32_t nodes_capacity, int32_t* node_count);
 
 /* ------------------------------------------------------------------ */
-/* Scene assembly: the ECS world + BuildAccelerateStructureSystem       */
+/* A flattened scene on the host: the eight upload buffers              */
 /* ------------------------------------------------------------------ */
 typedef struct rtamd_host_scene rtamd_host_scene;
 
 rtamd_host_scene* rtamd_host_scene_create(void);
 void rtamd_host_scene_destroy(rtamd_host_scene* s);
-
-/* BLASBaker.BuildBLASBlobAssetReference (RayTraceableBaker.cs:75-149): copies
- * the mesh, builds per-triangle AABBs + centres and the BLAS.  tree = 0: the
- * reference's median builder, 1: the SAH builder.  Returns the blob handle
- * (>= 0) or a negative status.  Baking the same mesh once and instancing the
- * handle is the reference's blob de-duplication (:59-65). */
-int rtamd_host_bake_blas(rtamd_host_scene* s, const float* positions, const float* normals,
-                         int32_t n_vertices, const int32_t* indices, int32_t n_triangles, int32_t tree);
-
-/* One entity with RayTraceableBLASComponent + RayTraceableMaterialComponent +
- * LocalToWorld (column-major).  Returns the entity index (= object index =
- * entityIndexInQuery) or a negative status. */
-int rtamd_host_add_entity(rtamd_host_scene* s, int32_t blas_handle, const float local_to_world[16],
-                          const float albedo[4], const float specular[4], const float emission[4]);
-int rtamd_host_set_entity_transform(rtamd_host_scene* s, int32_t entity, const float local_to_world[16]);
-
-/* BuildAccelerateStructureSystem.OnUpdate (:41-163): world AABBs, TLAS build,
- * BLAS index assignment by first use, offsets, flattening, object properties
- * (WorldToLocal = inverse(LocalToWorld)). */
-int rtamd_host_scene_update(rtamd_host_scene* s);
-
-/* Builder of the TLAS in rtamd_host_scene_update: 0 (default) the reference's three-job
- * median build (BoundingVolumeHierarchyBuilder.cs:482-527), which its own fixed-size
- * arrays limit to roughly 1 300 objects (the update then fails with a message instead
- * of overrunning them as the reference would); 1 the binned-SAH builder, any count. */
-int rtamd_host_scene_set_tlas_builder(rtamd_host_scene* s, int32_t tree);
 
 typedef struct rtamd_host_buffers {
     const rtamd_node* tlas; int32_t n_tlas_nodes;
@@ -99,7 +54,7 @@ typedef struct rtamd_host_buffers {
     int32_t tlas_branch_count;
 } rtamd_host_buffers;
 
-/* The eight buffers of the last update; valid until the next update / destroy. */
+/* The eight buffers the scene holds (after a load, or an update by a producer); valid until the next load / update / destroy. */
 int rtamd_host_scene_buffers(const rtamd_host_scene* s, rtamd_host_buffers* out);
 
 /* ------------------------------------------------------------------ */

@@ -1,7 +1,9 @@
 """Compile the native libraries in-tree.
 
   raytracing_amd/lib/librtamd.so       HIP kernels + C ABI (hipcc, gfx950 only)
-  raytracing_amd/lib/librtamd_host.so  host-side helpers + the restated reference scene producers of tests/producers (g++, CPU only)
+  raytracing_amd/lib/librtamd_host.so  host-side helpers: mesh sources, image codecs, SAH tree writer, camera, scene file (g++, CPU only)
+  tests/producers/_build/librtamd_testhost.so   the reference's C# scene producers restated (tests/producers; built only where
+                                       that directory exists: fixtures, tests and synthetic bench inputs use it, the package does not)
   oracle/_build/librt_oracle.so        CPU oracle (g++; test infrastructure)
 
 Run as `python -m raytracing_amd.build` or through `__graft_entry__.build()`.
@@ -50,12 +52,9 @@ def build_device(force=False):
 
 def build_host(force=False):
     """librtamd_host.so: the package's own host helpers (mesh sources, image codecs, SAH tree writer,
-    camera, scene file: raytracing_amd/csrc/host) together with the restated reference producers that
-    only tests, fixtures and synthetic bench inputs use (tests/producers)."""
+    camera, scene container and scene file: raytracing_amd/csrc/host)."""
     hdir = os.path.join(CSRC, "host")
-    pdir = os.path.join(ROOT, "tests", "producers")
     srcs = sorted(os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith(".cpp"))
-    srcs += sorted(os.path.join(pdir, f) for f in os.listdir(pdir) if f.endswith(".cpp"))
     deps = srcs + [os.path.join(hdir, "host_internal.h"), os.path.join(CSRC, "wide_bvh.h"), os.path.join(INC, "rtamd.h"),
                    os.path.join(INC, "rtamd_host.h")]
     out = os.path.join(LIB, "librtamd_host.so")
@@ -63,6 +62,27 @@ def build_host(force=False):
         os.makedirs(LIB, exist_ok=True)
         _run([os.environ.get("CXX", "g++")] + CXX_FLAGS + ["-I" + INC, "-I" + hdir] + srcs + ["-o", out, "-lz"])
     return out
+
+
+PRODUCERS = os.path.join(ROOT, "tests", "producers")
+TESTHOST = os.path.join(PRODUCERS, "_build", "librtamd_testhost.so")
+
+
+def build_testhost(force=False):
+    """librtamd_testhost.so: the reference's BVH builder, bake and per-frame flattening restated in C++
+    (tests/producers).  Test and fixture infrastructure in a library of its own, which takes the scene
+    container, the SAH writer and the error text from librtamd_host.so; skipped where the tests are absent."""
+    if not os.path.isdir(PRODUCERS):
+        return None
+    hdir = os.path.join(CSRC, "host")
+    srcs = sorted(os.path.join(PRODUCERS, f) for f in os.listdir(PRODUCERS) if f.endswith(".cpp"))
+    host = build_host(force)
+    deps = srcs + [host, os.path.join(hdir, "host_internal.h"), os.path.join(INC, "rtamd.h"), os.path.join(INC, "rtamd_host.h")]
+    if force or _newer(TESTHOST, deps):
+        os.makedirs(os.path.dirname(TESTHOST), exist_ok=True)
+        _run([os.environ.get("CXX", "g++")] + CXX_FLAGS + ["-I" + INC, "-I" + hdir] + srcs +
+             ["-o", TESTHOST, "-L" + LIB, "-lrtamd_host", "-Wl,-rpath,$ORIGIN/../../../raytracing_amd/lib"])
+    return TESTHOST
 
 
 def build_oracle(force=False):
@@ -80,7 +100,7 @@ def build_oracle(force=False):
 
 
 def build_all(force=False):
-    return build_device(force), build_host(force), build_oracle(force)
+    return build_device(force), build_host(force), build_testhost(force), build_oracle(force)
 
 
 if __name__ == "__main__":

@@ -83,3 +83,8 @@ int bvhBuildSah(const rtamd_aabb* aabbs, int n, rtamd_node* nodes, int capacity,
 }
 
 }  // namespace rtamd_host
+
+extern "C" int rtamd_host_bvh_build_sah(const rtamd_aabb* aabbs, int32_t n, rtamd_node* nodes, int32_t cap, int32_t* node_count) {
+    if (!nodes || !node_count || (n > 0 && !aabbs)) return RTAMD_ERR_INVALID_ARG;
+    return rtamd_host::bvhBuildSah(aabbs, n, nodes, cap, node_count);
+}

@@ -80,6 +80,29 @@ void rtamd_host_camera(const float position[3], const float rot[4], float fovDeg
     out->Seed = 0; out->ReflectionNum = 1;
 }
 
+// ----------------------------------------------------------- scene container ----
+// A flattened scene held on the host: the eight upload buffers, filled by rtamd_host_scene_load (or by a
+// producer outside this library) and handed out as pointers.
+rtamd_host_scene* rtamd_host_scene_create(void) { return new (std::nothrow) rtamd_host_scene(); }
+
+void rtamd_host_scene_destroy(rtamd_host_scene* s) { delete s; }
+
+int rtamd_host_scene_buffers(const rtamd_host_scene* s, rtamd_host_buffers* out) {
+    if (!s || !out) return RTAMD_ERR_INVALID_ARG;
+    if (s->objects.empty()) return RTAMD_ERR_NO_SCENE;
+    out->tlas = s->tlas.data(); out->n_tlas_nodes = (int)s->tlas.size();
+    out->blas_offsets = s->blasOffsets.data();
+    out->blas = s->blasNodes.data(); out->n_blas_nodes = (int)s->blasNodes.size();
+    out->vertices_offsets = s->vtxOffsets.data();
+    out->vertices = s->vertices.data(); out->n_vertices = (int)s->vertices.size();
+    out->triangles_offsets = s->triOffsets.data();
+    out->triangles = s->triangles.data(); out->n_triangles = (int)s->triangles.size();
+    out->n_blas = s->nBlas;
+    out->objects = s->objects.data(); out->n_objects = (int)s->objects.size();
+    out->tlas_branch_count = s->branchCount;
+    return RTAMD_OK;
+}
+
 // ----------------------------------------------------------- scene file ----
 static const char kMagic[8] = {'R', 'T', 'A', 'M', 'D', 'S', 'C', '1'};
 

@@ -1,6 +1,9 @@
-"""Host-side scene producers (CPU): thin ctypes layer over librtamd_host.so.
+"""Host side (CPU): thin ctypes layer over librtamd_host.so — meshes, images, camera, the flattened-scene
+container and file, the SAH tree writer — and over the restated reference producers, which live in a
+library of their own (tests/producers -> librtamd_testhost.so: fixture infrastructure, loaded only when a
+producer class is used; the package's own helpers never need it).
 
-Class and method names mirror the reference's C# host code so that tests read like
+Class and method names of the producers mirror the reference's C# host code so that tests read like
 tests of that code:
 
   BoundingVolumeHierarchy.Build / .ScheduleBuildJobs   Assets/Script/BVH/BoundingVolumeHierarchyBuilder.cs:482-558
@@ -27,13 +30,7 @@ def lib():
         L.rtamd_host_last_error.restype = C.c_char_p
         L.rtamd_host_scene_create.restype = C.c_void_p
         L.rtamd_host_scene_destroy.argtypes = [C.c_void_p]
-        L.rtamd_host_bake_blas.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
-        L.rtamd_host_add_entity.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.rtamd_host_set_entity_transform.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
-        L.rtamd_host_scene_update.argtypes = [C.c_void_p]
         L.rtamd_host_scene_buffers.argtypes = [C.c_void_p, C.POINTER(T.HostBuffers)]
-        L.rtamd_host_bvh_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
-        L.rtamd_host_bvh_build_jobs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.rtamd_host_bvh_build_sah.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         L.rtamd_host_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
         L.rtamd_host_inverse4x4.argtypes = [C.c_void_p, C.c_void_p]
@@ -48,6 +45,32 @@ def lib():
         L.rtamd_host_scene_load.argtypes = [C.c_void_p, C.c_char_p]
         _lib = L
     return _lib
+
+
+_PRODUCERS_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "producers", "_build",
+                               "librtamd_testhost.so")
+_producers = None
+
+
+def producers():
+    """The restated reference producers (BVH builder, bake, per-frame flattening): test and fixture
+    infrastructure, not part of the package's own library."""
+    global _producers
+    if _producers is None:
+        lib()           # its scene container, SAH writer and error text are what the producers build on
+        if not os.path.exists(_PRODUCERS_PATH):
+            raise RuntimeError(f"{_PRODUCERS_PATH} is missing: the reference's scene producers are built from tests/producers "
+                               "by `python -m raytracing_amd.build`")
+        L = C.CDLL(_PRODUCERS_PATH)
+        L.rtamd_host_bake_blas.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
+        L.rtamd_host_add_entity.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rtamd_host_set_entity_transform.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.rtamd_host_scene_update.argtypes = [C.c_void_p]
+        L.rtamd_host_scene_set_tlas_builder.argtypes = [C.c_void_p, C.c_int32]
+        L.rtamd_host_bvh_build.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        L.rtamd_host_bvh_build_jobs.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        _producers = L
+    return _producers
 
 
 class HostError(RuntimeError):
@@ -148,7 +171,7 @@ class BoundingVolumeHierarchy:
         n = len(aabbs)
         nodes = np.zeros(n + 64, dtype=T.NODE)
         cnt = C.c_int32(0)
-        _check(lib().rtamd_host_bvh_build(_ptr(points), _ptr(aabbs), n, _ptr(nodes), len(nodes), C.byref(cnt)), "Build")
+        _check(producers().rtamd_host_bvh_build(_ptr(points), _ptr(aabbs), n, _ptr(nodes), len(nodes), C.byref(cnt)), "Build")
         return nodes[:cnt.value].copy()
 
     @staticmethod
@@ -159,7 +182,7 @@ class BoundingVolumeHierarchy:
         n = len(aabbs)
         nodes = np.zeros(n + 128, dtype=T.NODE)
         bc = C.c_int32(0)
-        _check(lib().rtamd_host_bvh_build_jobs(_ptr(points), _ptr(aabbs), n, _ptr(nodes), len(nodes), C.byref(bc)), "ScheduleBuildJobs")
+        _check(producers().rtamd_host_bvh_build_jobs(_ptr(points), _ptr(aabbs), n, _ptr(nodes), len(nodes), C.byref(bc)), "ScheduleBuildJobs")
         return nodes, bc.value
 
     @staticmethod
@@ -262,8 +285,7 @@ class BuildAccelerateStructureSystem:
             raise MemoryError("rtamd_host_scene_create")
         self.ObjectsCount = 0
         if tlas_tree != self.MEDIAN:
-            lib().rtamd_host_scene_set_tlas_builder.argtypes = [C.c_void_p, C.c_int32]
-            _check(lib().rtamd_host_scene_set_tlas_builder(self._s, tlas_tree), "set_tlas_builder")
+            _check(producers().rtamd_host_scene_set_tlas_builder(self._s, tlas_tree), "set_tlas_builder")
 
     def close(self):
         if self._s:
@@ -278,24 +300,24 @@ class BuildAccelerateStructureSystem:
 
     def BakeBLAS(self, mesh, tree=MEDIAN):
         """BLASBaker.BuildBLASBlobAssetReference: returns a blob handle; reuse it to instance the mesh."""
-        return _check(lib().rtamd_host_bake_blas(self._s, _ptr(mesh.positions), _ptr(mesh.normals), len(mesh.positions),
+        return _check(producers().rtamd_host_bake_blas(self._s, _ptr(mesh.positions), _ptr(mesh.normals), len(mesh.positions),
                                                  _ptr(mesh.indices), len(mesh.indices), tree), "BakeBLAS")
 
     def AddEntity(self, blas, local_to_world, albedo=(1, 1, 1, 1), specular=(0, 0, 0, 1), emission=(0, 0, 0, 1)):
         def c4(v):
             v = list(v)
             return _f32(v + [1.0] * (4 - len(v)), 4)
-        e = _check(lib().rtamd_host_add_entity(self._s, blas, _ptr(_f32(local_to_world, 16)), _ptr(c4(albedo)),
+        e = _check(producers().rtamd_host_add_entity(self._s, blas, _ptr(_f32(local_to_world, 16)), _ptr(c4(albedo)),
                                                _ptr(c4(specular)), _ptr(c4(emission))), "AddEntity")
         self.ObjectsCount = e + 1
         return e
 
     def SetLocalToWorld(self, entity, local_to_world):
-        _check(lib().rtamd_host_set_entity_transform(self._s, entity, _ptr(_f32(local_to_world, 16))), "SetLocalToWorld")
+        _check(producers().rtamd_host_set_entity_transform(self._s, entity, _ptr(_f32(local_to_world, 16))), "SetLocalToWorld")
 
     def OnUpdate(self):
         """Returns SceneBuffers (copies)."""
-        _check(lib().rtamd_host_scene_update(self._s), "OnUpdate")
+        _check(producers().rtamd_host_scene_update(self._s), "OnUpdate")
         hb = T.HostBuffers()
         _check(lib().rtamd_host_scene_buffers(self._s, C.byref(hb)), "buffers")
         return _buffers_from_host(hb)

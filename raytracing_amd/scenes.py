@@ -117,13 +117,13 @@ def _bumpy_sphere(segments, rings, seed):
     return H.Mesh(p.astype(np.float32), vn.astype(np.float32), tri)
 
 
-MODELS_NPZ = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "reference_models.npz")
+MODELS_NPZ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "reference_models.npz")
 
 
 def load_model(name, models_dir=None):
     """One of the reference's meshes (peter, bunny, cow: Assets/Models/*.dae) as the COLLADA loader
     reads it: from the .dae when `models_dir` holds it, otherwise from the committed arrays the
-    loader produced (tests/golden/reference_models.npz, written by tests/golden/make_golden.py)."""
+    loader produced (raytracing_amd/data/reference_models.npz, written by tests/golden/make_golden.py)."""
     if models_dir and os.path.exists(os.path.join(models_dir, name + ".dae")):
         return H.Mesh.load_dae(os.path.join(models_dir, name + ".dae"))
     z = np.load(MODELS_NPZ, allow_pickle=False)

@@ -16,6 +16,7 @@
 #include <memory>
 
 #include "host_internal.h"
+#include "rtamd_testhost.h"
 
 namespace rtamd_host {
 
@@ -46,20 +47,12 @@ int rtamd_host_bvh_build_jobs(rtamd_point_and_index* points, const rtamd_aabb* a
     if (!nodes || !points || !aabbs) return RTAMD_ERR_INVALID_ARG;
     return bvhBuildJobs(points, aabbs, n, nodes, cap, branch_count);
 }
-int rtamd_host_bvh_build_sah(const rtamd_aabb* aabbs, int32_t n, rtamd_node* nodes, int32_t cap, int32_t* node_count) {
-    if (!nodes || !node_count || (n > 0 && !aabbs)) return RTAMD_ERR_INVALID_ARG;
-    return bvhBuildSah(aabbs, n, nodes, cap, node_count);
-}
-
-rtamd_host_scene* rtamd_host_scene_create(void) { return new (std::nothrow) rtamd_host_scene(); }
 
 int rtamd_host_scene_set_tlas_builder(rtamd_host_scene* s, int32_t tree) {
     if (!s || (tree != 0 && tree != 1)) return RTAMD_ERR_INVALID_ARG;
     s->tlasTree = tree;
     return RTAMD_OK;
 }
-void rtamd_host_scene_destroy(rtamd_host_scene* s) { delete s; }
-
 // RayTraceableBaker.cs:75-149
 int rtamd_host_bake_blas(rtamd_host_scene* s, const float* positions, const float* normals, int32_t nVerts,
                          const int32_t* indices, int32_t nTris, int32_t tree) {
@@ -217,22 +210,6 @@ int rtamd_host_scene_update(rtamd_host_scene* s) {
         }
         std::memcpy(o.LocalToWorld, en.l2w, sizeof(o.LocalToWorld));
     }
-    return RTAMD_OK;
-}
-
-int rtamd_host_scene_buffers(const rtamd_host_scene* s, rtamd_host_buffers* out) {
-    if (!s || !out) return RTAMD_ERR_INVALID_ARG;
-    if (s->objects.empty()) return RTAMD_ERR_NO_SCENE;
-    out->tlas = s->tlas.data(); out->n_tlas_nodes = (int)s->tlas.size();
-    out->blas_offsets = s->blasOffsets.data();
-    out->blas = s->blasNodes.data(); out->n_blas_nodes = (int)s->blasNodes.size();
-    out->vertices_offsets = s->vtxOffsets.data();
-    out->vertices = s->vertices.data(); out->n_vertices = (int)s->vertices.size();
-    out->triangles_offsets = s->triOffsets.data();
-    out->triangles = s->triangles.data(); out->n_triangles = (int)s->triangles.size();
-    out->n_blas = s->nBlas;
-    out->objects = s->objects.data(); out->n_objects = (int)s->objects.size();
-    out->tlas_branch_count = s->branchCount;
     return RTAMD_OK;
 }
 

@@ -32,10 +32,25 @@ def test_librtamd_exports_every_declared_symbol():
 
 def test_librtamd_host_exports_every_declared_symbol():
     names = _declared("rtamd_host.h", "rtamd_host_")
-    assert len(names) >= 20
+    assert len(names) >= 18
     L = host.lib()
     for n in names:
         assert hasattr(L, n), n
+
+
+def test_restated_reference_producers_are_a_library_of_their_own():
+    """The reference's builder, bake and per-frame system restated (tests/producers) are fixture
+    infrastructure: declared in their own header, exported by librtamd_testhost.so and by nothing else."""
+    text = open(os.path.join(ROOT, "tests", "producers", "rtamd_testhost.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(rtamd_host_\w+)\s*\(", text)))
+    assert len(names) == 7
+    P = host.producers()
+    out = subprocess.run(["nm", "-D", "--defined-only", host._LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    for n in names:
+        assert hasattr(P, n), n
+        assert n not in exported, f"{n} is still exported by the product's host library"
 
 
 def test_struct_layouts_match_reference_strides(oracle):
