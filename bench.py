@@ -7,8 +7,10 @@ and framebuffers resident in HBM.
   N = 1   BASELINE.json configs[2]: the triangle-mesh scene built from the reference's
           Assets/Models (peter / bunny / cow subdivided to 1 051 936 triangles, each mesh its
           own BLAS, plus the sub-scene's emissive walls) at 1920x1080, 256 spp, 8 bounces.
-          The random-spheres scene of configs[1] (1080p, 64 spp) is measured as well and
-          reported inside the same line ("other_workloads").
+          Measured as well and reported inside the same line ("other_workloads"): the random-spheres
+          scene of configs[1] (1080p, 64 spp), the 50 M-instanced-triangle scene of configs[4] (1080p, 64 spp),
+          and REF mode -- what the reference's shader renders, one primary and one mirror ray per pixel
+          (Assets/Shaders/RayTracingShader.compute:413-429) -- as milliseconds per rtamd_render call.
   N > 1   BASELINE.json configs[3]: the same scene at 3840x2160, 1024 spp in total, STRONG
           scaling by tile sharding (one process per GPU, launched by torch.distributed.run):
           rank r renders the 32x32-pixel tiles t with t % N == r into a zeroed frame, and the
@@ -97,9 +99,15 @@ def roofline_for(rt, frame, W, Hh, out, args, workload, spp, kernel_ms_avg, sum_
     tflops = alg_flops / secs / 1e12
     # offline evidence of the same step: rocprofv3 --pmc passes (tools/gpu_pmc.sh, tools/summarise_pmc.py)
     # and the streaming ceilings of the cache levels (tools/l2_stream.hip)
+    # (kept only when the record was measured on the kernels that are running: the library and the record both
+    # carry the fingerprint of the device sources)
+    from raytracing_amd import backend
     pmc = None
     rec = load_json("pmc_step.json")
-    if rec:
+    lib_sha = backend.source_sha()
+    pmc_sha = (rec or {}).get("kernel_source_sha")
+    pmc_current = bool(rec) and pmc_sha == lib_sha
+    if rec and pmc_current:
         for r in rec.get("workloads", []):
             if r.get("workload") == workload and r.get("spp") == spp and r.get("width") == W and r.get("height") == Hh:
                 pmc = r
@@ -119,7 +127,8 @@ def roofline_for(rt, frame, W, Hh, out, args, workload, spp, kernel_ms_avg, sum_
                                       "frac": gi / VALU_ISSUE_PEAK_GINST, "lane_utilisation": pmc.get("valu_lane_utilisation"),
                                       "what": "VALU wave instructions of the step (PMC SQ_INSTS_VALU) / kernel time against 1024 SIMDs x 1 per 4 cycles"}
         if pmc.get("l2_read_bytes_per_step") and ceil:
-            level = "l2_0.2MB" if workload == "spheres" else "mall_84MB"
+            # gather ceiling of the cache level the scene's nodes and triangles live in
+            level = {"spheres": "l2_0.2MB", "instanced": "mall_84MB"}.get(workload, "mall_84MB")
             # one node of the micro-benchmark = one 128-byte line request (it reads 112 bytes of it)
             peak = ceil.get(level, {}).get("gather_nodes_per_s", 0.0) * 128.0 / 1e9
             if peak:
@@ -140,8 +149,11 @@ def roofline_for(rt, frame, W, Hh, out, args, workload, spp, kernel_ms_avg, sum_
             "bytes_per_ray": alg_bytes / max(1, rays), "flops_per_ray": alg_flops / max(1, rays),
             "nodes_per_ray": per_ray["nodes"], "tris_per_ray": per_ray["tris"], "instances_per_ray": per_ray["instances"],
             "counted_on": f"{cspp} spp of the same frame, scaled by ray segments",
-            "pmc_offline": {k: pmc[k] for k in ("simd_valu_issue_frac", "valu_lane_utilisation", "l2_hit_rate", "l1_accesses_per_cu_cycle",
-                                                "wave_cycles_waiting_frac", "salu_per_valu", "source") if pmc and k in pmc} or None}
+            "pmc_offline": ({k: pmc[k] for k in ("simd_valu_issue_frac", "valu_lane_utilisation", "l2_hit_rate", "l1_accesses_per_cu_cycle",
+                                                 "wave_cycles_waiting_frac", "salu_per_valu", "source") if k in pmc} if pmc else None),
+            "pmc_record": {"kernel_source_sha": pmc_sha, "library_source_sha": lib_sha, "current": pmc_current,
+                           "note": None if pmc_current else "profiles/pmc_step.json was measured on other kernel sources than the library that ran: "
+                                                            "its counter-derived ceilings and `traffic` are left out of this line"}}
 
 
 def timed_steps(step, steps, warmup, sync, barrier):
@@ -159,6 +171,88 @@ def timed_steps(step, steps, warmup, sync, barrier):
     sync()
     barrier()
     return time.perf_counter() - t0, acc, r
+
+
+def ref_mode_frames(rt, frame, W, Hh, out, frames=100):
+    """REF mode: what the reference's shader renders (one primary and one mirror ray per covered pixel,
+    Assets/Shaders/RayTracingShader.compute:413-429), one blocking rtamd_render call per frame as
+    CustomRenderPass.Execute makes it (RayTracingPass.cs:101), frame in device memory."""
+    import torch
+    from raytracing_amd import types as T
+    for _ in range(5):
+        rt.Execute(frame, W, Hh, out_rgba=out, mode=T.MODE_REF)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    km = hm = 0.0
+    r = None
+    for _ in range(frames):
+        r = rt.Execute(frame, W, Hh, out_rgba=out, mode=T.MODE_REF)
+        km += r["kernel_ms"]
+        hm += r["handover_ms"]
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / frames * 1e3
+    return {"resolution": [W, Hh], "frames": frames, "ms_per_render_call": ms, "kernels_ms": km / frames,
+            "handover_ms": hm / frames, "handover_pixels": r["handover_pixels"], "ray_segments": r["rays"],
+            "value": r["rays"] / ms / 1e3, "unit": "Mrays/s"}
+
+
+def pt_workload(rt, name, args, dev, kernel_name, steps):
+    """One more path-traced workload on the same context: scene up, timed steps, roofline."""
+    import torch
+    from raytracing_amd import types as T
+    (buf, frame, sky), desc = build_workload(name, 1920, 1080, args.tree)
+    rt.SetScene(buf)
+    rt.SetSkyBox(sky)
+    out = torch.zeros((1080, 1920, 4), dtype=torch.float32, device=dev)
+    spp = DEFAULT_SPP[name]
+
+    def step():
+        return rt.Execute(frame, 1920, 1080, out_rgba=out, mode=T.MODE_PT, spp=spp, max_bounces=args.bounces, seed=args.seed)
+    e, a, last = timed_steps(step, steps, 1, torch.cuda.synchronize, lambda: None)
+    rec = {"workload": f"{desc}, 1920x1080, {spp} spp, {args.bounces} bounces", "value": a["rays"] / e / 1e6,
+           "unit": "Mrays/s", "ms_per_step": e / steps * 1e3, "steps": steps,
+           "roofline": None if args.no_counters else roofline_for(
+               rt, frame, 1920, 1080, out, args, name, spp, a["trace_ms"] / steps,
+               a["kernel_ms"] / steps - a["handover_ms"] / steps - a["trace_ms"] / steps, a["handover_ms"] / steps, last, kernel_name)}
+    return rec, frame, out
+
+
+def secondary_workloads(rt, frame, out, args, dev, kernel_name, roofline):
+    """The other configurations of the one-GPU line, on the same context (the mesh scene is still up on entry)."""
+    import torch
+    from raytracing_amd import types as T
+    steps = max(2, args.steps)
+    others = {}
+    ref = {"what": "REF mode = the reference shader's own image (primary ray + one mirror ray per covered pixel, RayTracingShader.compute:413-429): "
+                   "wall-clock milliseconds per blocking rtamd_render call, frame in device memory; handover_ms is the part spent in the "
+                   "reference-order kernel on the pixels the production kernel passed on"}
+    ref["mesh_1080p"] = ref_mode_frames(rt, frame, 1920, 1080, out)
+    out4 = torch.zeros((2160, 3840, 4), dtype=torch.float32, device=dev)      # (same aspect: the same frame record)
+    ref["mesh_4k"] = ref_mode_frames(rt, frame, 3840, 2160, out4, frames=50)
+    del out4
+    if roofline is not None and args.tree == 0:
+        # BASELINE configs[2] says "with SAH BVH": the reference-order work counts of the same scene when the
+        # caller's trees are SAH trees instead of the reference's median-split ones (kernel time does not depend on
+        # the caller's trees, the library rebuilds them; the algorithmic counts do)
+        (bs, fs, ss), _ = build_workload("mesh", 1920, 1080, 1)
+        rt.SetScene(bs)
+        c = rt.Execute(fs, 1920, 1080, out_rgba=out, counters=True, mode=T.MODE_PT, spp=8, max_bounces=args.bounces, seed=args.seed)["counters"]
+        n = max(1, c["rays"])
+        per = {k: c[k] / n for k in ("nodes", "tris", "instances", "hits")}
+        fl = 100 * per["nodes"] + 56 * per["tris"] + 30 * per["instances"]
+        by = 116 * per["nodes"] + 48 * per["tris"] + 180 * per["instances"] + 36 * per["hits"]
+        roofline["caller_sah_trees"] = {"nodes_per_ray": per["nodes"], "tris_per_ray": per["tris"], "instances_per_ray": per["instances"],
+                                        "flops_per_ray": fl, "bytes_per_ray": by,
+                                        "fp32_valu_frac_on_these_counts": fl * (roofline["algorithmic_flops_per_step"] / max(1e-9, roofline["flops_per_ray"]))
+                                        / (roofline["kernel_ms"] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                        "what": "reference-order counts of the same frame (8 spp) with the caller's BLAS and TLAS built by the SAH "
+                                                "builder (--tree 1) instead of the reference's median split"}
+        del bs
+    others["spheres"], frame2, out2 = pt_workload(rt, "spheres", args, dev, kernel_name, steps)
+    ref["spheres_1080p"] = ref_mode_frames(rt, frame2, 1920, 1080, out2)
+    others["instanced"], _, _ = pt_workload(rt, "instanced", args, dev, kernel_name, steps)
+    others["ref"] = ref
+    return others
 
 
 def main():
@@ -276,23 +370,8 @@ def main():
         if not args.no_counters:
             roofline = roofline_for(rt, frame, W, Hh, out, args, args.workload, spp, kernel_ms_avg, sum_ms_avg, handover_ms_avg, last, kernel_name)
         others = None
-        if not multi and not args.no_secondary and args.workload == "mesh":
-            # configs[1], the random-spheres scene at 1080p / 64 spp, on the same context
-            (buf2, frame2, sky2), desc2 = build_workload("spheres", 1920, 1080, args.tree)
-            rt.SetScene(buf2)
-            rt.SetSkyBox(sky2)
-            out2 = torch.zeros((1080, 1920, 4), dtype=torch.float32, device=dev)
-            spp2 = DEFAULT_SPP["spheres"]
-
-            def step2():
-                return rt.Execute(frame2, 1920, 1080, out_rgba=out2, mode=T.MODE_PT, spp=spp2, max_bounces=args.bounces, seed=args.seed)
-            e2, a2, l2 = timed_steps(step2, max(2, args.steps), 1, torch.cuda.synchronize, lambda: None)
-            n2 = max(2, args.steps)
-            others = {"spheres": {"workload": f"{desc2}, 1920x1080, {spp2} spp, {args.bounces} bounces", "value": a2["rays"] / e2 / 1e6,
-                                  "unit": "Mrays/s", "ms_per_step": e2 / n2 * 1e3, "steps": n2,
-                                  "roofline": None if args.no_counters else roofline_for(
-                                      rt, frame2, 1920, 1080, out2, args, "spheres", spp2, a2["trace_ms"] / n2,
-                                      a2["kernel_ms"] / n2 - a2["handover_ms"] / n2 - a2["trace_ms"] / n2, a2["handover_ms"] / n2, l2, kernel_name)}}
+        if not multi and not inproc and not args.no_secondary and args.workload == "mesh":
+            others = secondary_workloads(rt, frame, out, args, dev, kernel_name, roofline)
         base = None
         if not args.no_cpu_baseline and not multi:
             base = cpu_baseline(buf, frame, sky, W, Hh, spp, args.bounces, args.seed)

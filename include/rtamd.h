@@ -243,22 +243,26 @@ int rtamd_render(rtamd_ctx* ctx, const rtamd_frame_cbuffer* frame,
                  const rtamd_ext_params* ext, int32_t width, int32_t height,
                  float* out_rgba, int32_t* out_prim_id);
 
-/* rtamd_render for callers that cannot allocate device memory: code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the
- * reference.  Same arguments, same image bit for bit, but the call allocates and frees
- * nothing: its working memory (work-queue head, ray counter, the mask and list of pixels
- * handed to the reference-order kernel, the tile list, hand-over samples) is a fixed
- * 5 526 272-byte array that each GPU the library runs on holds until the process ends.
+/* rtamd_render for callers that cannot allocate device memory: tight serving loops,
+ * harnesses that forbid hipMalloc, hosts that budget device memory themselves.  No
+ * counterpart in the reference.  Same arguments, same image bit for bit, but the call
+ * allocates and frees nothing: its working memory (work-queue head, ray counter, the mask and
+ * list of pixels handed to the reference-order kernel, the tile list, hand-over samples, and a
+ * 16 MiB overflow area for the traversal stacks) is a fixed 22 303 488-byte array that each GPU
+ * the library runs on holds until the process ends.  The call still synchronises its stream,
+ * reads a small block back to the host and decides there whether a hand-over pass follows, so
+ * it cannot be recorded into a HIP graph.
  * Limits (RTAMD_ERR_INVALID_ARG beyond them): width*height <= 3840*2160 and at most 8192
  * tiles of 32x32 pixels; spp <= 262144; out_rgba, out_prim_id and ext->out_t must be
  * device memory (or NULL); RTAMD_FLAG_ACCUMULATE only once rtamd_render has created the
  * running sum at this size.  At most 65536 pixels of a frame may need the reference-order
  * kernel (RTAMD_ERR_OUT_OF_MEMORY otherwise; typical frames need about a hundred, a REF
  * frame one row and one column).  PT mode runs one path per lane here (the path pool
- * needs buffers sized to the frame).  A traversal stack deeper than the 24 entries kept
- * on chip has no overflow area in this variant: such pixels go to the reference-order
- * kernel.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU
- * (two contexts, two threads, two streams) race. */
+ * needs buffers sized to the frame).  Traversal stacks keep 16 entries on chip and, on a
+ * 256-CU part, 16 more in the fixed overflow area (32 in all; the deepest stack of the
+ * benchmark scenes is 27): a pixel with a deeper stack goes to the reference-order kernel.
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two contexts,
+ * two threads, two streams) race. */
 int rtamd_render_noalloc(rtamd_ctx* ctx, const rtamd_frame_cbuffer* frame,
                          const rtamd_ext_params* ext, int32_t width, int32_t height,
                          float* out_rgba_device, int32_t* out_prim_id_device);
@@ -310,7 +314,7 @@ int rtamd_composite_add(rtamd_ctx* ctx, const float* src_rgba, uint8_t* dst_rgba
 int rtamd_present(rtamd_ctx* ctx, const float* src_rgba, uint8_t* dst_rgba8, int32_t width,
                   int32_t height, int32_t tonemap, float exposure, float gamma);
 
-/* Library / build identification, e.g. "rtamd 0.1 gfx950". */
+/* Library / build identification: "rtamd 0.3 gfx950 src:<fingerprint of the sources it was built from>". */
 const char* rtamd_version(void);
 
 #ifdef __cplusplus

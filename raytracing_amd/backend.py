@@ -61,6 +61,12 @@ def lib():
     return _lib
 
 
+def source_sha():
+    """The fingerprint of the sources the loaded librtamd.so was built from (see build.source_sha)."""
+    v = lib().rtamd_version().decode()
+    return v.split("src:")[1] if "src:" in v else "unstamped"
+
+
 def _ptr(a):
     if a is None:
         return None

@@ -36,17 +36,35 @@ def _run(cmd):
     subprocess.run(cmd, check=True)
 
 
+def device_sources():
+    return sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))] + [os.path.join(INC, "rtamd.h")])
+
+
+def source_sha():
+    """Fingerprint of the device library's sources (12 hex digits of a SHA-256 over their names and contents).  It is
+    compiled into the library (rtamd_version) and written into every kept hardware-counter record, so that a
+    measurement can be told from one of other kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in device_sources():
+        h.update(os.path.basename(p).encode() + b"\0")
+        h.update(open(p, "rb").read())
+    extra = os.environ.get("RTAMD_EXTRA_HIPFLAGS", "")
+    if extra:
+        h.update(b"flags:" + extra.encode())
+    return h.hexdigest()[:12]
+
+
 def build_device(force=False):
     src = os.path.join(CSRC, "rtamd.hip")
     tlas_src = os.path.join(CSRC, "tlas_build.hip")
-    deps = [src, tlas_src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
-    deps += [os.path.join(INC, "rtamd.h")]
+    deps = device_sources()
     out = os.path.join(LIB, "librtamd.so")
     if force or _newer(out, deps):
         os.makedirs(LIB, exist_ok=True)
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         extra = os.environ.get("RTAMD_EXTRA_HIPFLAGS", "").split()      # experiments only
-        _run([hipcc] + HIP_FLAGS + extra + ["-I" + INC, "-I" + CSRC, src, tlas_src, "-o", out])
+        _run([hipcc] + HIP_FLAGS + extra + ['-DRTAMD_SOURCE_SHA="' + source_sha() + '"', "-I" + INC, "-I" + CSRC, src, tlas_src, "-o", out])
     return out
 
 

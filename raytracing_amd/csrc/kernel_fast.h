@@ -84,6 +84,10 @@ struct FastSceneHost {
     int nInst = 0;
     int tlasRoot = 0;
     int maxDepth = 0;
+    // of the device this scene lives on (set when its context is created): compute units, and the largest
+    // batch of paths whose sample buffers take a reasonable share of the device's memory
+    int numCU = 0;
+    size_t poolPathCap = (size_t)1 << 27;
 
     // who builds the tree over the instances: 0 = by instance count, 1 = host (binned SAH), 2 = device (Morton order)
     int tlasBuildMode = 0;
@@ -778,11 +782,14 @@ inline void chooseThresholds(FastLaunchConfig& cfg, const FastSceneHost& fs, int
 }
 
 // Device memory the caller lends to one launch in place of the context's growable buffers (the
-// allocation-free entry point): room for the tile list; there is no stack overflow area then,
-// a stack deeper than LDS hands its pixel to the reference-order kernel at once.
+// allocation-free entry point): room for the tile list and a fixed stack overflow area, shared out
+// among the lanes of the grid (16 entries per lane on a 256-CU part: stacks of up to 32 entries, the
+// deepest of the benchmark scenes is 27; a deeper one hands its pixel to the reference-order kernel).
 struct LaunchScratch {
     int32_t* superTiles;
     int32_t superCap;
+    int32_t* stackSpill;
+    size_t spillWords;
 };
 
 inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs& a, hipStream_t stream, const LaunchScratch* lent = nullptr) {
@@ -804,13 +811,8 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
     } else e = fs.superTiles.put(fs.hSuper, stream);
     if (e != hipSuccess) return e;
 
-    static int numCU = 0;
-    if (!numCU) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
-        numCU = prop.multiProcessorCount;
-    }
+    const int numCU = fs.numCU;
+    if (numCU <= 0) return hipErrorInvalidDevice;
     FastLaunchConfig cfg = fastLaunchConfig();
     chooseThresholds(cfg, fs, a.mode == RTAMD_MODE_PT ? kModePt : kModeRef);
     FastLaunchConfig primaryCfg = fastLaunchConfig();
@@ -825,7 +827,13 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
     sc.nodes = fs.nodes.p; sc.inst = fs.inst.p; sc.shade = fs.shade.p;
     sc.tris = fs.tris.p; sc.nrms = fs.nrms.p; sc.triOrig = fs.triOrig.p; sc.nSuperTiles = (int)fs.hSuper.size();
     sc.tlasRoot = fs.tlasRoot;
-    if (lent) { sc.superTiles = lent->superTiles; sc.stackSpill = nullptr; sc.spillMax = 0; }
+    if (lent) {
+        sc.superTiles = lent->superTiles;
+        // (the kernel indexes the area by gridDim.x: whole chunks per lane of the grid actually launched)
+        const size_t perLane = lent->spillWords / ((size_t)grid * kBlockThreads);
+        sc.spillMax = (int32_t)(perLane > (size_t)kSpillMax ? (size_t)kSpillMax : perLane) / kSpillChunk * kSpillChunk;
+        sc.stackSpill = sc.spillMax > 0 ? lent->stackSpill : nullptr;
+    }
     else {
         sc.superTiles = fs.superTiles.p;
         if ((e = fs.stackSpill.ensure((size_t)kSpillMax * (size_t)(numCU * cfg.blocksPerCU) * kBlockThreads)) != hipSuccess) return e;

@@ -604,19 +604,19 @@ struct PoolHost {
 
 // Paths per launch.  Every launch has a fixed cost (the pool fills, and drains while the slowest paths end: 1.7 ms
 // on the 1M-triangle scene), so a batch is as large as memory reasonably allows: 2^29 paths (2 x 8 GB of samples
-// for a frame of several batches) when that is at most an eighth of the device's memory, 2^27 at least.
-inline size_t poolMaxPaths() {
-    // (worked out once; contexts of several devices may ask at the same time from their own host threads)
-    static const size_t byMemory = []() -> size_t {
-        size_t paths = (size_t)1 << 27;
-        size_t freeB = 0, totalB = 0;
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess)
-            while (paths < ((size_t)1 << 29) && 2 * (2 * paths) * sizeof(float4) <= totalB / 8) paths *= 2;
-        else
-            (void)hipGetLastError();
-        return paths;
-    }();
-    size_t cap = byMemory;
+// for a frame of several batches) when that is at most an eighth of the device's memory, 2^27 at least.  Worked
+// out per context, with its device current, when the context is created.
+inline size_t poolMaxPathsForCurrentDevice() {
+    size_t paths = (size_t)1 << 27;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess)
+        while (paths < ((size_t)1 << 29) && 2 * (2 * paths) * sizeof(float4) <= totalB / 8) paths *= 2;
+    else
+        (void)hipGetLastError();
+    return paths;
+}
+inline size_t poolMaxPaths(const FastSceneHost& fs) {
+    size_t cap = fs.poolPathCap;
     if (const char* s = getenv("RTAMD_POOL_MAX_PATHS")) { long long v = atoll(s); if (v >= 1024) cap = (size_t)v; }
     if (cap > ((size_t)1 << 31)) cap = (size_t)1 << 31;       // (a path's place in its batch is a 32-bit number)
     return cap;
@@ -640,13 +640,8 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     hipError_t e = fs.superTiles.put(fs.hSuper, stream);
     if (e != hipSuccess) return e;
 
-    static int numCU = 0;
-    if (!numCU) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
-        numCU = prop.multiProcessorCount;
-    }
+    const int numCU = fs.numCU;
+    if (numCU <= 0) return hipErrorInvalidDevice;
     FastLaunchConfig cfg = fastLaunchConfig();
     FastLaunchConfig primaryCfg = cfg;
     chooseThresholds(primaryCfg, fs, kModePrimary);
@@ -703,7 +698,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     if ((e = ph.recs.ensure((size_t)gridMax * (kBlockThreads / 64) * kPoolSlots)) != hipSuccess) return e;
     if ((e = ph.pathList.ensure((size_t)2 * PoolHost::kPathCap)) != hipSuccess) return e;
     size_t tilesPerChunk = 0, workPerChunk = 0, samplesPerBatch = 0;
-    for (size_t cap = poolMaxPaths();; cap /= 2) {
+    for (size_t cap = poolMaxPaths(fs);; cap /= 2) {
         tilesPerChunk = cap / 1024;
         if (tilesPerChunk < 1) tilesPerChunk = 1;
         if (tilesPerChunk > fs.hSuper.size()) tilesPerChunk = fs.hSuper.size();

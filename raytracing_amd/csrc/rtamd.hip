@@ -70,8 +70,10 @@ constexpr size_t kNaOffRedoMask = kCtrlBytes;       // one bit per pixel
 constexpr size_t kNaOffRedoList = kNaOffRedoMask + (size_t)(kNaMaxPixels / 32) * 4;
 constexpr size_t kNaOffSuperTiles = kNaOffRedoList + (size_t)kNaRedoCap * 4;
 constexpr size_t kNaOffSamples = kNaOffSuperTiles + (size_t)kNaMaxTiles * 4;
-constexpr size_t kNaBytes = kNaOffSamples + (size_t)kNaSampleCap * 16;      // 5 526 272 bytes
-static_assert(kNaOffRedoList % 256 == 0 && kNaOffSuperTiles % 256 == 0 && kNaOffSamples % 256 == 0, "scratch pieces are 256-byte aligned");
+constexpr size_t kNaOffSpill = kNaOffSamples + (size_t)kNaSampleCap * 16;   // overflow of the LDS traversal stacks: [entry][lane of the grid]
+constexpr size_t kNaSpillWords = (size_t)16 * 256 * 1024;                   // 16 entries for each lane of 256 workgroups of 1024 (a larger grid gets fewer entries per lane)
+constexpr size_t kNaBytes = kNaOffSpill + kNaSpillWords * 4;                // 22 303 488 bytes
+static_assert(kNaOffRedoList % 256 == 0 && kNaOffSuperTiles % 256 == 0 && kNaOffSamples % 256 == 0 && kNaOffSpill % 256 == 0, "scratch pieces are 256-byte aligned");
 
 }  // namespace
 
@@ -245,7 +247,11 @@ int render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_param
 
 extern "C" {
 
-const char* rtamd_version(void) { return "rtamd 0.2 gfx950"; }
+#ifndef RTAMD_SOURCE_SHA
+#define RTAMD_SOURCE_SHA "unstamped"
+#endif
+// (the fingerprint of the sources this library was built from: raytracing_amd/build.py, source_sha)
+const char* rtamd_version(void) { return "rtamd 0.3 gfx950 src:" RTAMD_SOURCE_SHA; }
 
 const char* rtamd_last_error_string(const rtamd_ctx* ctx) {
     return ctx ? ctx->error.c_str() : g_createError.c_str();
@@ -273,6 +279,12 @@ int rtamd_ctx_create(int device_ordinal, rtamd_ctx** out_ctx) {
         return rc;
     }
     c->stream = c->ownStream;
+    if ((e = hipDeviceGetAttribute(&c->fast.numCU, hipDeviceAttributeMultiprocessorCount, device_ordinal)) != hipSuccess || c->fast.numCU <= 0) {
+        int rc = failHip(nullptr, e == hipSuccess ? hipErrorInvalidDevice : e, "compute-unit count of the device");
+        rtamd_ctx_destroy(c);
+        return rc;
+    }
+    c->fast.poolPathCap = rt::poolMaxPathsForCurrentDevice();
     c->fast.hSuper.reserve((size_t)kNaMaxTiles);     // the tile list of a launch never grows the heap after this
     *out_ctx = c;
     return RTAMD_OK;
@@ -500,7 +512,7 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
     unsigned long long* const dRayCount = (unsigned long long*)(ctrl + kNaOffRayCount);
     int32_t* const dErrorFlag = (int32_t*)(ctrl + kNaOffErrorFlag);
     int32_t* const dRedoCount = (int32_t*)(ctrl + kNaOffRedoCount);
-    const rt::LaunchScratch lent = {(int32_t*)(na + kNaOffSuperTiles), kNaMaxTiles};
+    const rt::LaunchScratch lent = {(int32_t*)(na + kNaOffSuperTiles), kNaMaxTiles, (int32_t*)(na + kNaOffSpill), kNaSpillWords};
 
     rt::RenderArgs a;
     std::memset(&a, 0, sizeof(a));

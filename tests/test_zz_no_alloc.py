@@ -54,6 +54,33 @@ def test_noalloc_entry_equals_render(mode):
         p.Dispose()
 
 
+@pytest.mark.parametrize("scene", ["mesh", "instanced"])
+def test_noalloc_entry_on_scenes_with_deep_traversal_stacks(scene):
+    """Stacks on these scenes outgrow the 16 entries kept on chip (22 and 27 entries at full size): the fixed
+    overflow area carries them, so the call succeeds, hands over no more pixels than rtamd_render does,
+    and gives the same image."""
+    from raytracing_amd import backend, scenes
+    w, h = 480, 270
+    if scene == "mesh":
+        buf, frame, sky = scenes.mesh_scene(w, h, target_tris=165_256)
+    else:
+        buf, frame, sky = scenes.instanced_scene(w, h, instances=400, tris_per_blas=20_000)
+    p = backend.RayTracingPass(0)
+    try:
+        p.SetScene(buf)
+        p.SetSkyBox(sky)
+        for kw in (dict(mode=T.MODE_REF), dict(mode=T.MODE_PT, spp=2, max_bounces=6, seed=5)):
+            a = _render(p, "render", frame, w, h, **kw)
+            b = _render(p, "noalloc", frame, w, h, **kw)
+            assert b[3]["free_delta"] == 0
+            assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
+            assert a[3]["rays"] == b[3]["rays"] and a[3]["rays"] > 0
+            # (PT through rtamd_render hands over single paths, here whole pixels: at most one pixel per path)
+            assert b[3]["handover_pixels"] <= max(a[3]["handover_pixels"], 8) + 600, (a[3]["handover_pixels"], b[3]["handover_pixels"])
+    finally:
+        p.Dispose()
+
+
 def test_noalloc_entry_rejects_what_it_cannot_serve():
     import torch
     from raytracing_amd import backend, scenes

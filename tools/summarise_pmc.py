@@ -78,7 +78,13 @@ if __name__ == "__main__":
         for spec in sys.argv[4:]:
             tag, wl, w, h, spp = spec.split(":")
             recs.append(step_record(tag, wl, int(w), int(h), int(spp), source))
-        json.dump({"workloads": recs}, open(out, "w"), indent=1)
-        print(json.dumps({"workloads": recs}, indent=1))
+        sys.path.insert(0, ROOT)
+        from raytracing_amd import build as B
+        doc = {"kernel_source_sha": B.source_sha(),
+               "what": "hardware-counter totals of one bench step per workload; kernel_source_sha is the fingerprint of the device "
+                       "sources they were measured on (rtamd_version of the library prints the same when it was built from them)",
+               "workloads": recs}
+        json.dump(doc, open(out, "w"), indent=1)
+        print(json.dumps(doc, indent=1))
     else:
         print(json.dumps({t: summarise(t) for t in sys.argv[1:]}, indent=1))
