@@ -293,6 +293,24 @@ int rtamd_last_trace_kernel_ms(const rtamd_ctx* ctx, float* trace_ms);
  * handover_ms).  No counterpart in the reference. */
 int rtamd_last_handover_stats(const rtamd_ctx* ctx, float* handover_ms, int32_t* pixels);
 
+/* The guard of the production kernels' distance culling.  The reference tests a leaf slot when
+ * the slot's box is entered before the closest hit found so far
+ * (Assets/Shaders/RayTracingShader.compute:298,327); the production kernels visit boxes in
+ * another order and cull them against the closest hit times (1 + 2^-8), which returns the
+ * reference's triangle as long as no triangle's own boxes are entered, as computed, more than
+ * 2^-8 (relative) behind its own computed hit distance -- rounding error, a few ulps on ordinary
+ * meshes, larger on extreme slivers and huge coordinates.  Every hit the kernels compute is
+ * checked against a quarter of that slack (2^-10): such a ray goes to the reference-order kernel
+ * and the hit's mesh is marked; from then on (until the next rtamd_scene_upload) every ray
+ * entering an instance of a marked mesh goes to the reference-order kernel, and the frame in
+ * which it happened is rendered a second time before rtamd_render returns (not a frame with
+ * RTAMD_FLAG_ACCUMULATE, whose samples are in the running sum already).
+ *   hits_near_slack  such hits in the last rtamd_render call (first pass)
+ *   demoted_meshes   meshes (BLAS) of the scene currently handled in reference order
+ *   rerendered       1 when the last call rendered its frame twice
+ * Any pointer may be NULL.  No counterpart in the reference. */
+int rtamd_last_guard_stats(const rtamd_ctx* ctx, int32_t* hits_near_slack, int32_t* demoted_meshes, int32_t* rerendered);
+
 /* Presentation step of the reference: AddShader's `Blend SrcAlpha One`
  * (Assets/Shaders/AddShader.shader:11,43-46) onto an 8-bit UNORM target
  * (RayTracingPass.cs:58): dst = saturate(dst + src.rgb * src.a), quantised to

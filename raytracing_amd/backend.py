@@ -16,7 +16,7 @@ _lib = None
 
 EXPORTS = ["rtamd_ctx_create", "rtamd_ctx_create_multi", "rtamd_multi_info", "rtamd_multi_exchange_note", "rtamd_ctx_destroy", "rtamd_last_error_string", "rtamd_scene_upload",
            "rtamd_scene_refresh_objects", "rtamd_sky_upload", "rtamd_render", "rtamd_render_noalloc", "rtamd_accum_reset",
-           "rtamd_set_stream", "rtamd_set_tlas_build", "rtamd_tlas_info", "rtamd_last_render_stats", "rtamd_last_trace_kernel_ms", "rtamd_last_handover_stats", "rtamd_composite_add", "rtamd_present", "rtamd_version"]
+           "rtamd_set_stream", "rtamd_set_tlas_build", "rtamd_tlas_info", "rtamd_last_render_stats", "rtamd_last_trace_kernel_ms", "rtamd_last_handover_stats", "rtamd_last_guard_stats", "rtamd_composite_add", "rtamd_present", "rtamd_version"]
 
 
 class BackendError(RuntimeError):
@@ -56,6 +56,7 @@ def lib():
         L.rtamd_last_render_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
         L.rtamd_last_handover_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.rtamd_last_trace_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.rtamd_last_guard_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.rtamd_composite_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         _lib = L
     return _lib
@@ -164,6 +165,12 @@ class RayTracingPass:
         n, lv, dev = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         self._check(lib().rtamd_tlas_info(self._ctx, C.byref(n), C.byref(lv), C.byref(dev)))
         return {"nodes": n.value, "levels": lv.value, "built_on_device": bool(dev.value)}
+
+    def GuardStats(self):
+        """The culling guard after the last Execute (rtamd_last_guard_stats)."""
+        h, m, r = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._check(lib().rtamd_last_guard_stats(self._ctx, C.byref(h), C.byref(m), C.byref(r)))
+        return {"hits_near_slack": h.value, "demoted_meshes": m.value, "rerendered": bool(r.value)}
 
     def ResetAccumulation(self):
         self._check(lib().rtamd_accum_reset(self._ctx))

@@ -16,13 +16,18 @@ struct alignas(128) WNode {
 };
 struct alignas(64) FTri { float4 a, b, c, d; };
 struct alignas(16) FNrm { float4 a, b, c; };                            // n0.xyz n1.x | n1.yz n2.xy | n2.z
-struct alignas(32) FInst { float4 r0, r1, r2; float4 bxy; float blz, bhz; int32_t root, object; float4 pad; };   // TLAS slot box as (lo, hi) pairs: bxy = lo.x, hi.x, lo.y, hi.y
+struct alignas(32) FInst { float4 r0, r1, r2; float4 bxy; float blz, bhz; int32_t root, object; float4 pad; };   // TLAS slot box as (lo, hi) pairs: bxy = lo.x, hi.x, lo.y, hi.y;
+                                                                                                                   // object | kDemotedBit; pad.x = bits of the BLAS index
 struct alignas(32) FShade { float4 r0, r1, r2; float4 albedo, specular, emission; };
 
 // child / stack words: >= 0 node index; < 0: ~payload, payload bit 30 set = instance rank,
 // clear = (first triangle << 2 | count-1).  kEmptyChild never reaches the stack.
 constexpr int32_t kEmptyChild = (int32_t)0x80000001;
 constexpr uint32_t kInstanceBit = 0x40000000u;
+// FInst::object bit: the instance's mesh is one on which the distance culling of the production kernels was seen
+// to come close to its slack (see RT_GUARD_FACTOR): every ray that enters the instance is handed to the
+// reference-order kernel.
+constexpr int32_t kDemotedBit = 1 << 30;
 
 struct FastScene {
     const WNode* nodes;

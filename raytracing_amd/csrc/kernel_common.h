@@ -16,7 +16,19 @@ struct RefScene {
     const int32_t* triOffsets;
     const rtamd_int3* tris;
     const rtamd_object_property* objects;
+    // The guard of the production kernels' distance culling (RT_GUARD_FACTOR, kernel_fast.h), kept by the
+    // reference-order kernels, which trace what the production kernels hand over: *guardCount counts the hits
+    // whose own boxes are entered, as computed, more than 2^-10 behind the hit's computed distance,
+    // guardBlas[b] is set for every BLAS b such a hit lay in.  Either may be null.
+    int32_t* guardCount;
+    int32_t* guardBlas;
 };
+
+// A hit whose own boxes are entered, as computed, more than this factor behind the hit's computed distance trips
+// the guard of the production kernels' distance culling (see RT_CULL_RELAX in kernel_fast.h).
+#ifndef RT_GUARD_FACTOR
+#define RT_GUARD_FACTOR 1.0009765625f   /* 1 + 2^-10 */
+#endif
 
 struct Sky {
     const float4* texels;

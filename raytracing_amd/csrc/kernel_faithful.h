@@ -41,12 +41,21 @@ __device__ __forceinline__ bool refSlab(const rtamd_node& n, int i, const Ray& r
     return nearMax <= farMin;
 }
 
+// Entry distance of the same test (its nearMax).
+__device__ __forceinline__ float refSlabNear(const rtamd_node& n, int i, const Ray& ray) {
+    float nearXt = (n.Lx[i] - ray.origin.x) * ray.invDir.x, farXt = (n.Hx[i] - ray.origin.x) * ray.invDir.x;
+    float nearYt = (n.Ly[i] - ray.origin.y) * ray.invDir.y, farYt = (n.Hy[i] - ray.origin.y) * ray.invDir.y;
+    float nearZt = (n.Lz[i] - ray.origin.z) * ray.invDir.z, farZt = (n.Hz[i] - ray.origin.z) * ray.invDir.z;
+    return fmax_(fmax_(fmax_(fmin_(nearXt, farXt), fmin_(nearYt, farYt)), fmin_(nearZt, farZt)), 0.0f);
+}
+
 // IntersectBLAS, .compute:277-346 (position / normal / material are derived after the
 // traversal from the surviving (t,u,v,object,triangle); they are pure functions of it).
 // The four-box mask is evaluated once per node with the distance at that time (:298);
 // hits accepted while walking a leaf's slots do not re-filter its later slots.
+// instNear: entry distance of the instance's TLAS slot box (for the guard of the production kernels' culling only).
 __device__ __forceinline__ void refIntersectBlas(const RefScene& sc, const Ray& ray, int index, HitRec& best,
-                                                 int32_t* stack, LocalCounters& cnt, bool twoSided) {
+                                                 int32_t* stack, LocalCounters& cnt, bool twoSided, float instNear) {
     const rtamd_object_property& prop = sc.objects[index];
     int blasIndex = prop.BLASIndex;
     int blasOffset = sc.blasOffsets[blasIndex];
@@ -90,6 +99,11 @@ __device__ __forceinline__ void refIntersectBlas(const RefScene& sc, const Ray& 
                     float t, u, v;
                     bool back;
                     if (trisect(localRay.origin, localRay.direction, v0, v1 - v0, v2 - v0, t, u, v, twoSided, back)) {
+                        // not part of the reference: the guard of the production kernels' distance culling (RT_GUARD_FACTOR)
+                        if (fmax_(refSlabNear(node, i, localRay), instNear) > t * RT_GUARD_FACTOR) {
+                            if (sc.guardCount) atomicAdd(sc.guardCount, 1);
+                            if (sc.guardBlas) atomicOr(sc.guardBlas + blasIndex, 1);
+                        }
                         if (t > 0 && t < best.t) {
                             cnt.hits++;
                             best.t = t; best.u = u; best.v = v;
@@ -131,7 +145,7 @@ __device__ __forceinline__ HitRec refIntersectTlas(const RefScene& sc, const Ray
                     if ((uint32_t)top > cnt.maxTlas) cnt.maxTlas = top;
                 }
             } else if (data != -1) {
-                refIntersectBlas(sc, ray, data, best, blasStack, cnt, twoSided);
+                refIntersectBlas(sc, ray, data, best, blasStack, cnt, twoSided, refSlabNear(node, i, ray));
             }
         }
     } while (top > 0);

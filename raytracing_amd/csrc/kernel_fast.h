@@ -80,6 +80,8 @@ struct FastSceneHost {
     int tlasReserve = 0, nTlasNodes = 0;
     std::vector<int32_t> hSlotOf;      // per instance (visiting order): TLAS node << 2 | leaf slot
     DBuf<int32_t> slotOf, dBlasRoot;
+    DBuf<int32_t> guardBlas;           // per BLAS: marked by the culling guard (RT_GUARD_FACTOR); cleared by a scene upload, kept over object refreshes
+    int nBlasOfScene = 0;
     std::vector<int32_t> hSuper;
     int nInst = 0;
     int tlasRoot = 0;
@@ -96,7 +98,7 @@ struct FastSceneHost {
 
     void release() {
         nodes.release(); inst.release(); shade.release(); tris.release(); nrms.release(); triOrig.release();
-        superTiles.release(); stackSpill.release(); stats.release(); slotOf.release(); dBlasRoot.release();
+        superTiles.release(); stackSpill.release(); stats.release(); slotOf.release(); dBlasRoot.release(); guardBlas.release();
         tlasDeviceDestroy(tlasBuilder);
         tlasBuilder = nullptr;
     }
@@ -296,6 +298,9 @@ struct FastSceneHost {
         nBlasNodes = hNodes.size() - (size_t)tlasReserve;
         blasUploaded = false;
         hipError_t e;
+        nBlasOfScene = nBlas;
+        if ((e = guardBlas.ensure((size_t)nBlas)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(guardBlas.p, 0, (size_t)nBlas * sizeof(int32_t), stream)) != hipSuccess) return e;
         if ((e = tris.put(ft, stream)) != hipSuccess) return e;
         if ((e = nrms.put(fn, stream)) != hipSuccess) return e;
         if ((e = triOrig.put(orig, stream)) != hipSuccess) return e;
@@ -361,12 +366,17 @@ struct FastSceneHost {
         } else if (!onDevice && (e = hipMemcpyAsync(nodes.p, hNodes.data(), (size_t)nTlasNodes * sizeof(WNode), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
         if ((e = slotOf.put(hSlotOf, stream)) != hipSuccess) return e;
         if ((e = inst.ensure((size_t)nInst)) != hipSuccess || (e = shade.ensure((size_t)nInst)) != hipSuccess) return e;
-        if ((e = tlasPackInstances(dTlas, dObjects, slotOf.p, dBlasRoot.p, nInst, inst.p, shade.p, stream)) != hipSuccess) return e;
+        if ((e = tlasPackInstances(dTlas, dObjects, slotOf.p, dBlasRoot.p, guardBlas.p, nInst, inst.p, shade.p, stream)) != hipSuccess) return e;
         if (onDevice) {
             if (!tlasBuilder && !(tlasBuilder = tlasDeviceCreate())) return hipErrorOutOfMemory;
             return tlasDeviceBuild(tlasBuilder, inst.p, nInst, nodes.p, tlasReserve, stream, &nTlasNodes, &tlasDepth);
         }
         return hipSuccess;
+    }
+    // The culling guard marked a mesh during a render: the per-instance records are written again, now with
+    // kDemotedBit on every instance of a marked mesh (the tree over the instances does not change).
+    hipError_t applyDemotions(const rtamd_node* dTlas, const rtamd_object_property* dObjects, hipStream_t stream) {
+        return tlasPackInstances(dTlas, dObjects, slotOf.p, dBlasRoot.p, guardBlas.p, nInst, inst.p, shade.p, stream);
     }
     static constexpr int kTlasDeviceMin = 4096;   // instances from which the device build is used when the caller does not choose
     int tlasDepth = 0;
@@ -460,6 +470,16 @@ __device__ __forceinline__ float slabNear(float lo_x, float hi_x, float lo_y, fl
 #ifndef RT_CULL_RELAX
 #define RT_CULL_RELAX 1.00390625f   /* 1 + 2^-8 */
 #endif
+// The guard of that slack.  Culling against best.t * RT_CULL_RELAX can only hide a triangle whose own boxes (leaf
+// slot box, instance box) are entered, as computed, more than 2^-8 (relative) behind the triangle's own computed hit
+// distance: in exact arithmetic a box is never entered behind what it holds, so this is rounding error of the two
+// computations, a few ulps on ordinary meshes and growing with the aspect of slivers.  Every hit the production
+// kernels compute is checked: entered more than 2^-10 behind its distance (a quarter of the slack), the ray is
+// handed to the reference-order kernel (four instructions per hit, no branch).  The reference-order kernels make the
+// same check on the hits they compute, count such hits and mark the hit's mesh; the host then lets every ray that
+// enters an instance of a marked mesh go to the reference-order kernel (kDemotedBit) and renders the frame again
+// (rtamd.hip, rtamd_last_guard_stats).
+// (RT_GUARD_FACTOR itself is defined in kernel_common.h: both families of kernels use it)
 
 __device__ __forceinline__ void cswap(float& da, int32_t& ca, float& db, int32_t& cb) {
     bool sw = db < da;
@@ -493,7 +513,7 @@ __device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world
     s.albedoW = fs.albedo.w; s.specularW = fs.specular.w;
     s.back = (h.tri & kBackFaceBit) != 0;
     if (s.back) s.normal = v3(-s.normal.x, -s.normal.y, -s.normal.z);
-    s.object = fi.object;
+    s.object = fi.object & ~kDemotedBit;
     s.triangle = sc.triOrig[tri];
     return s;
 }

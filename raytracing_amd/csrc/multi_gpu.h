@@ -19,16 +19,68 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstdint>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace rt {
+
+// One host thread per further device of a context over several GPUs, kept for the life of the context: a frame
+// posts one job to each (the per-device calls block) and waits for all of them.
+class DeviceWorker {
+public:
+    DeviceWorker() : th_([this] { run(); }) {}
+    ~DeviceWorker() {
+        { std::lock_guard<std::mutex> hold(m_); quit_ = true; }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    DeviceWorker(const DeviceWorker&) = delete;
+    DeviceWorker& operator=(const DeviceWorker&) = delete;
+    void post(std::function<int()> job) {
+        { std::lock_guard<std::mutex> hold(m_); job_ = std::move(job); pending_ = true; done_ = false; }
+        cv_.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> hold(m_);
+        cv_.wait(hold, [this] { return done_; });
+        return rc_;
+    }
+
+private:
+    void run() {
+        for (;;) {
+            std::function<int()> job;
+            {
+                std::unique_lock<std::mutex> hold(m_);
+                cv_.wait(hold, [this] { return pending_ || quit_; });
+                if (quit_ && !pending_) return;
+                job = std::move(job_);
+                pending_ = false;
+            }
+            int rc;
+            try { rc = job(); } catch (...) { rc = -1000; }      // (reported as an internal error by the caller)
+            { std::lock_guard<std::mutex> hold(m_); rc_ = rc; done_ = true; }
+            cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<int()> job_;
+    bool pending_ = false, quit_ = false, done_ = true;
+    int rc_ = 0;
+    std::thread th_;      // (last: starts when everything above exists)
+};
 
 struct RcclApi {
     void* handle = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;       // optional: used to drop communicators after a failed call
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -47,6 +99,7 @@ struct RcclApi {
         auto sym = [&](const char* n) { void* p = dlsym(handle, n); if (!p) { ok = false; why = std::string("librccl lacks ") + n; } return p; };
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        CommAbort = (decltype(CommAbort))dlsym(handle, "ncclCommAbort");
         CommCount = (decltype(CommCount))sym("ncclCommCount");
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");

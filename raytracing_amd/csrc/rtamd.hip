@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -65,7 +66,8 @@ constexpr size_t kNaOffErrorFlag = 80;
 constexpr size_t kNaOffRedoCount = 84;
 constexpr size_t kCtrlBytes = 256;                  // the block of small words in front (what a render clears and reads back)
 constexpr size_t kNaOffPathCount = 88;              // paths handed to the reference-order kernel: this batch, whole render, the batch in the other half of the buffers (3 x 4 B)
-constexpr size_t kCtrlUsed = 100;
+constexpr size_t kNaOffGuardCount = 100;            // hits that came within a quarter of the culling slack (RT_GUARD_FACTOR)
+constexpr size_t kCtrlUsed = 104;
 constexpr size_t kNaOffRedoMask = kCtrlBytes;       // one bit per pixel
 constexpr size_t kNaOffRedoList = kNaOffRedoMask + (size_t)(kNaMaxPixels / 32) * 4;
 constexpr size_t kNaOffSuperTiles = kNaOffRedoList + (size_t)kNaRedoCap * 4;
@@ -145,12 +147,14 @@ struct rtamd_ctx {
     DevBuf<int32_t> redoList;
     DevBuf<float4> redoSamples;
     int32_t lastRedoPixels = 0;
+    int32_t lastGuardHits = 0, lastGuardRerendered = 0, demotedMeshes = 0;      // the culling guard: see rtamd_last_guard_stats
     float lastKernelMs = 0.f, lastHandoverMs = 0.f, lastTraceMs = 0.f;
     uint64_t lastRays = 0;
 
     // A context over several GPUs (rtamd_ctx_create_multi) owns one ordinary context per device and
     // nothing else on the GPUs; subs[0] is the device the finished frame is assembled on.
     std::vector<rtamd_ctx*> subs;
+    std::vector<std::unique_ptr<rt::DeviceWorker>> workers;   // host thread of subs[d], d >= 1 (subs[0] runs on the caller's thread)
     std::vector<ncclComm_t> comms;                    // per sub, when RCCL carries the exchange
     int rcclRanks = 0;
     std::string exchangeNote;                         // why RCCL is not in use, if it is not
@@ -294,6 +298,7 @@ int rtamd_ctx_create(int device_ordinal, rtamd_ctx** out_ctx) {
 int rtamd_ctx_destroy(rtamd_ctx* c) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (!c->subs.empty()) {
+        c->workers.clear();        // (joins the per-device host threads)
         for (ncclComm_t comm : c->comms) if (comm) (void)rt::rccl().CommDestroy(comm);
         for (size_t d = 0; d < c->subs.size(); d++) {
             (void)hipSetDevice(c->subs[d]->device);
@@ -418,6 +423,7 @@ int rtamd_scene_upload(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas, cons
     HIP_TRY(c, c->tris.upload(tris, nTris, c->stream));
     c->nBlasNodes = nBlasNodes; c->nVerts = nVerts; c->nTris = nTris;
 
+    c->demotedMeshes = 0;
     std::string err;
     hipError_t e = c->fast.buildBottom(blasOffsets, blas, nodeCnt.data(), vtxOffsets, verts, triOffsets, tris,
                                        triCnt.data(), nBlas, nObjects, c->stream, err);
@@ -477,7 +483,7 @@ int rtamd_accum_reset(rtamd_ctx* c) {
 // One render.  noAlloc: working memory comes from this GPU's `scratch` array instead of the
 // context's growable buffers, outputs must be device memory, and nothing is allocated or freed.
 static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_params* ext, int32_t width,
-                      int32_t height, float* out_rgba, int32_t* out_prim_id, const bool noAlloc) {
+                      int32_t height, float* out_rgba, int32_t* out_prim_id, const bool noAlloc, const bool afterGuard = false) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (!frame) return fail(c, RTAMD_ERR_INVALID_ARG, "frame is NULL");
     if (width <= 0 || height <= 0 || width > (1 << 20) || height > (1 << 20) || (int64_t)width * height > (1ll << 30)) return fail(c, RTAMD_ERR_INVALID_ARG, "bad image size");
@@ -591,6 +597,7 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
     rt::RefScene rsc;
     rsc.tlas = c->tlas.p; rsc.blasOffsets = c->blasOffsets.p; rsc.blas = c->blas.p; rsc.vtxOffsets = c->vtxOffsets.p;
     rsc.verts = c->verts.p; rsc.triOffsets = c->triOffsets.p; rsc.tris = c->tris.p; rsc.objects = c->objects.p;
+    rsc.guardCount = (int32_t*)(ctrl + kNaOffGuardCount); rsc.guardBlas = c->fast.guardBlas.p;
     HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
     if (a.tileW > 0 && a.tileH > 0) {
         if (faithful) {
@@ -678,6 +685,37 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
         c->lastRedoPixels = redo + (usedPool ? paths : 0);
     }
     c->lastHandoverMs = handoverMs;
+    {
+        // The culling guard (RT_GUARD_FACTOR, kernel_fast.h).  The rays it fired on were handed over one by one and are
+        // exact; but a mesh that comes this close to the slack may also have hidden a hit from the kernel unseen.  Every
+        // instance of the marked meshes is switched to the reference-order kernel (until the next scene upload) and
+        // the frame is rendered once more.  A frame that adds to the running sum is not (its samples are in the sum
+        // already): there the switch takes effect from the next frame on.
+        int32_t guardHits = 0;
+        std::memcpy(&guardHits, c->hostCtrl + kNaOffGuardCount, sizeof(guardHits));
+        if (!afterGuard) { c->lastGuardHits = guardHits; c->lastGuardRerendered = 0; }
+        if (guardHits > 0 && !afterGuard && !faithful) {
+            // (on a scene with marked meshes the reference-order kernel sees such hits in every frame: only a newly
+            // marked mesh changes anything)
+            std::vector<int32_t> marked((size_t)c->fast.nBlasOfScene, 0);
+            HIP_TRY(c, hipMemcpyAsync(marked.data(), c->fast.guardBlas.p, marked.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            int32_t nowMarked = 0;
+            for (int32_t m : marked) nowMarked += m != 0;
+            const bool newlyMarked = nowMarked > c->demotedMeshes;
+            c->demotedMeshes = nowMarked;
+            if (newlyMarked) HIP_TRY(c, c->fast.applyDemotions(c->tlas.p, c->objects.p, c->stream));
+            if (newlyMarked && getenv("RTAMD_VERBOSE"))
+                fprintf(stderr, "[rtamd] culling guard: %d hits within a quarter of the slack; %d of %d meshes now go to the reference-order kernel\n", guardHits,
+                        c->demotedMeshes, c->fast.nBlasOfScene);
+            const bool addsToSum = e.mode == RTAMD_MODE_PT && (e.flags & RTAMD_FLAG_ACCUMULATE);
+            if (newlyMarked && !addsToSum) {
+                const int rc = renderCore(c, frame, ext, width, height, out_rgba, out_prim_id, noAlloc, true);
+                c->lastGuardRerendered = 1;
+                return rc;
+            }
+        }
+    }
     if (getenv("RTAMD_VERBOSE"))
         fprintf(stderr, "[rtamd] render %dx%d mode %d: %.3f ms, %d pixels handed to the reference-order kernel; nodes %zu (BLAS %zu), depth BLAS %d TLAS %d, instances %d\n",
                 width, height, a.mode, ms, redo, c->fast.hNodes.size(), c->fast.nBlasNodes, c->fast.maxDepth, c->fast.tlasDepth, c->fast.nInst);
@@ -697,24 +735,31 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
 // ---------------------------------------------------------------- several GPUs behind one context
 namespace multi {
 
-// Run `call` on every per-device context, each on a host thread of its own (the calls block);
-// the first failure is reported with that device's message.
+// Run `call` on every per-device context, each on its own host thread (the calls block; the threads live as long
+// as the context); the first failure is reported with that device's message.
 template <typename F>
 int forEach(rtamd_ctx* c, F call) {
     const size_t n = c->subs.size();
     std::vector<int> rc(n, RTAMD_OK);
-    std::vector<std::thread> th;
-    try {
-        for (size_t d = 1; d < n; d++) th.emplace_back([&, d] { rc[d] = call(c->subs[d]); });
-    } catch (...) {
-        for (auto& t : th) t.join();
-        return fail(c, RTAMD_ERR_OUT_OF_MEMORY, "could not start a host thread per device");
-    }
-    rc[0] = call(c->subs[0]);
-    for (auto& t : th) t.join();
-    for (size_t d = 0; d < n; d++)
+    for (size_t d = 1; d < n; d++) c->workers[d]->post([&call, c, d]() -> int { return call(c->subs[d]); });
+    try { rc[0] = call(c->subs[0]); } catch (...) { rc[0] = -1000; }
+    for (size_t d = 1; d < n; d++) rc[d] = c->workers[d]->wait();
+    for (size_t d = 0; d < n; d++) {
+        if (rc[d] == -1000) return fail(c, RTAMD_ERR_HIP, "device " + std::to_string(c->subs[d]->device) + ": internal error (exception on the device's host thread)");
         if (rc[d] != RTAMD_OK) return fail(c, rc[d], "device " + std::to_string(c->subs[d]->device) + ": " + c->subs[d]->error);
+    }
     return RTAMD_OK;
+}
+
+// RCCL failed at run time: give its communicators up and let peer copies carry the exchange from here on.
+static void dropRccl(rtamd_ctx* c, const std::string& why) {
+    rt::RcclApi& api = rt::rccl();
+    for (ncclComm_t comm : c->comms)
+        if (comm) (void)(api.CommAbort ? api.CommAbort(comm) : api.CommDestroy(comm));
+    c->comms.clear();
+    c->rcclRanks = 0;
+    c->exchangeNote = why + "; peer copies carry the exchange from that frame on";
+    if (getenv("RTAMD_VERBOSE")) fprintf(stderr, "[rtamd] %s\n", c->exchangeNote.c_str());
 }
 
 #define RCCL_TRY(c, expr)                                                                                 \
@@ -729,14 +774,18 @@ static int gatherPieces(rtamd_ctx* c, const std::vector<size_t>& bytes) {
     rtamd_ctx* root = c->subs[0];
     if (!c->comms.empty()) {
         rt::RcclApi& api = rt::rccl();
-        RCCL_TRY(c, api.GroupStart());
-        for (size_t d = 1; d < n; d++) {
-            if (!bytes[d]) continue;
-            RCCL_TRY(c, api.Recv(c->recv[d].p, bytes[d], ncclUint8, (int)d, c->comms[0], root->stream));
-            RCCL_TRY(c, api.Send(c->piece[d].p, bytes[d], ncclUint8, 0, c->comms[d], c->subs[d]->stream));
+        ncclResult_t r = getenv("RTAMD_RCCL_FAIL") ? ncclInternalError /* (tests: as if the first call had failed) */ : api.GroupStart();
+        if (r == ncclSuccess) {
+            for (size_t d = 1; d < n && r == ncclSuccess; d++) {
+                if (!bytes[d]) continue;
+                r = api.Recv(c->recv[d].p, bytes[d], ncclUint8, (int)d, c->comms[0], root->stream);
+                if (r == ncclSuccess) r = api.Send(c->piece[d].p, bytes[d], ncclUint8, 0, c->comms[d], c->subs[d]->stream);
+            }
+            const ncclResult_t e = api.GroupEnd();
+            if (r == ncclSuccess) r = e;
         }
-        RCCL_TRY(c, api.GroupEnd());
-        return RTAMD_OK;
+        if (r == ncclSuccess) return RTAMD_OK;
+        dropRccl(c, std::string("ncclSend / ncclRecv failed at run time (") + api.GetErrorString(r) + ")");
     }
     for (size_t d = 1; d < n; d++) {
         if (!bytes[d]) continue;
@@ -881,13 +930,20 @@ int render(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_param
         }
     } else if (n > 1 && out_rgba) {
         // reduce the sum buffers onto the first device
+        bool reduced = false;
         if (!c->comms.empty()) {
             rt::RcclApi& api = rt::rccl();
-            RCCL_TRY(c, api.GroupStart());
-            for (int d = 0; d < n; d++)
-                RCCL_TRY(c, api.Reduce(c->subs[d]->outRgba.p, d == 0 ? root->outRgba.p : nullptr, npix * 4, ncclFloat32, ncclSum, 0, c->comms[d], c->subs[d]->stream));
-            RCCL_TRY(c, api.GroupEnd());
-        } else {
+            ncclResult_t r = getenv("RTAMD_RCCL_FAIL") ? ncclInternalError : api.GroupStart();
+            if (r == ncclSuccess) {
+                for (int d = 0; d < n && r == ncclSuccess; d++)
+                    r = api.Reduce(c->subs[d]->outRgba.p, d == 0 ? root->outRgba.p : nullptr, npix * 4, ncclFloat32, ncclSum, 0, c->comms[d], c->subs[d]->stream);
+                const ncclResult_t e2 = api.GroupEnd();
+                if (r == ncclSuccess) r = e2;
+            }
+            if (r == ncclSuccess) reduced = true;
+            else dropRccl(c, std::string("ncclReduce failed at run time (") + api.GetErrorString(r) + ")");
+        }
+        if (!reduced) {
             HIP_TRY(c, c->recv[1].alloc(npix * sizeof(float4)));
             for (int d = 1; d < n; d++) {
                 HIP_TRY(c, hipSetDevice(c->subs[d]->device));
@@ -968,8 +1024,17 @@ int rtamd_ctx_create_multi(const int32_t* device_ordinals, int32_t n_devices, rt
         c->subs.push_back(sub);
         for (int k = 0; k < d; k++) distinct = distinct && device_ordinals[k] != device_ordinals[d];
     }
-    c->piece.resize((size_t)n_devices);
-    c->recv.resize((size_t)n_devices < 2 ? 2 : (size_t)n_devices);
+    try {
+        c->workers.resize((size_t)n_devices);
+        for (int d = 1; d < n_devices; d++) c->workers[(size_t)d] = std::make_unique<rt::DeviceWorker>();
+        c->piece.resize((size_t)n_devices);
+        c->recv.resize((size_t)n_devices < 2 ? 2 : (size_t)n_devices);
+    } catch (...) {
+        c->workers.clear();
+        for (rtamd_ctx* made : c->subs) (void)rtamd_ctx_destroy(made);
+        delete c;
+        return fail(nullptr, RTAMD_ERR_OUT_OF_MEMORY, "could not start a host thread per device");
+    }
     // peer access for the copies that carry the exchange when RCCL does not
     for (int d = 1; d < n_devices; d++)
         if (device_ordinals[d] != device_ordinals[0]) {
@@ -1036,6 +1101,23 @@ int rtamd_last_handover_stats(const rtamd_ctx* c, float* ms, int32_t* pixels) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (ms) *ms = c->lastHandoverMs;
     if (pixels) *pixels = c->lastRedoPixels;
+    return RTAMD_OK;
+}
+
+int rtamd_last_guard_stats(const rtamd_ctx* c, int32_t* hits_near_slack, int32_t* demoted_meshes, int32_t* rerendered) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    int32_t hits = c->lastGuardHits, meshes = c->demotedMeshes, again = c->lastGuardRerendered;
+    if (!c->subs.empty()) {
+        hits = meshes = again = 0;
+        for (const rtamd_ctx* sub : c->subs) {
+            hits += sub->lastGuardHits;
+            meshes = sub->demotedMeshes > meshes ? sub->demotedMeshes : meshes;
+            again |= sub->lastGuardRerendered;
+        }
+    }
+    if (hits_near_slack) *hits_near_slack = hits;
+    if (demoted_meshes) *demoted_meshes = meshes;
+    if (rerendered) *rerendered = again;
     return RTAMD_OK;
 }
 

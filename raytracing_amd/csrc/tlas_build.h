@@ -30,6 +30,7 @@ hipError_t tlasDeviceBuild(TlasDeviceBuilder* b, const FInst* inst, int n, WNode
 // device memory: instance r is the one in leaf slot (slotOf[r] & 3) of TLAS node (slotOf[r] >> 2);
 // blasRoot maps a BLAS index to the root of its tree in the production kernel's node array.
 hipError_t tlasPackInstances(const rtamd_node* tlas, const rtamd_object_property* objects, const int32_t* slotOf,
-                             const int32_t* blasRoot, int n, FInst* inst, FShade* shade, hipStream_t stream);
+                             const int32_t* blasRoot, const int32_t* blasDemoted /* per BLAS, may be null */, int n, FInst* inst, FShade* shade,
+                             hipStream_t stream);
 
 }  // namespace rt

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kCollapseThreads) void kTlasCollapse(const FInst* i
 // Per-instance records of the production kernel from the caller's arrays as uploaded: instance r
 // sits in leaf slot (slotOf[r] & 3) of TLAS node (slotOf[r] >> 2).
 __global__ __launch_bounds__(kThreads) void kTlasPack(const rtamd_node* tlas, const rtamd_object_property* objects, const int32_t* slotOf,
-                                                      const int32_t* blasRoot, int n, FInst* inst, FShade* shade) {
+                                                      const int32_t* blasRoot, const int32_t* blasDemoted, int n, FInst* inst, FShade* shade) {
     const int r = blockIdx.x * kThreads + threadIdx.x;
     if (r >= n) return;
     const int32_t code = slotOf[r];
@@ -338,8 +338,9 @@ __global__ __launch_bounds__(kThreads) void kTlasPack(const rtamd_node* tlas, co
     fi.r2 = make_float4(m[2], m[6], m[10], m[14]);
     fi.bxy = make_float4(nd.Lx[i], nd.Hx[i], nd.Ly[i], nd.Hy[i]);
     fi.blz = nd.Lz[i]; fi.bhz = nd.Hz[i];
-    fi.root = blasRoot[o.BLASIndex]; fi.object = d;
-    fi.pad = make_float4(0.f, 0.f, 0.f, 0.f);
+    fi.root = blasRoot[o.BLASIndex];
+    fi.object = d | (blasDemoted && blasDemoted[o.BLASIndex] ? kDemotedBit : 0);      // (a mesh the culling guard marked: fast_layout.h)
+    fi.pad = make_float4(__int_as_float(o.BLASIndex), 0.f, 0.f, 0.f);
     inst[r] = fi;
     FShade fs;
     const float* l = o.LocalToWorld;
@@ -388,10 +389,10 @@ void tlasDeviceDestroy(TlasDeviceBuilder* b) {
 }
 
 hipError_t tlasPackInstances(const rtamd_node* tlas, const rtamd_object_property* objects, const int32_t* slotOf,
-                             const int32_t* blasRoot, int n, FInst* inst, FShade* shade, hipStream_t stream) {
+                             const int32_t* blasRoot, const int32_t* blasDemoted, int n, FInst* inst, FShade* shade, hipStream_t stream) {
     if (!tlas || !objects || !slotOf || !blasRoot || !inst || !shade || n < 1) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kTlasPack, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, tlas, objects, slotOf,
-                       blasRoot, n, inst, shade);
+                       blasRoot, blasDemoted, n, inst, shade);
     return hipGetLastError();
 }
 

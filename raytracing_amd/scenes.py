@@ -368,3 +368,70 @@ def glass_scene(width=640, height=360):
     buf = sys.OnUpdate()
     sys.close()
     return buf, look_at_camera((0.3, 1.8, -5.5), (0.2, 0.5, 0), 40.0, width, height), procedural_sky()
+
+
+def quat_axis_angle_np(axis, degrees):
+    a = np.asarray(axis, dtype=np.float64)
+    a = a / np.linalg.norm(a)
+    h = np.radians(degrees) / 2
+    return np.array([*(a * np.sin(h)), np.cos(h)])
+
+
+def _quat_matrix(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def needle_comb_scene(w, h, needles=6000, length=4.0, aspect=2.0e4, layers=2, layer_gap=2.0e-3, tilt_deg=25.0, skew_deg=0.002, inplane_deg=41.0, seed=0):
+    """Built to strain the production kernels' distance culling beyond its slack: `layers` flat sheets of needle
+    triangles (aspect `aspect`: long edges `length`, width length / aspect) lying `layer_gap` apart, the needles
+    oblique to the axes within the sheet.  Moeller-Trumbore's determinant on such a triangle is a difference of
+    products some `aspect` times larger than itself, so the computed hit distance is off by about 2^-24 times
+    that, while the triangle's box is thin along the view and its computed entry distance is good to an ulp:
+    the box is entered, as computed, behind the hit.  The sheets lie close enough that such errors decide
+    which sheet a ray hits first."""
+    rs = np.random.RandomState(50 + seed)
+    wd = length / aspect
+    pos, idx = [], []
+    for layer in range(layers):
+        z = layer * layer_gap
+        x0 = -0.5 * needles * wd
+        base = len(pos)
+        for i in range(needles + 1):
+            pos.append((x0 + i * wd, -0.5 * length, z))                  # bottom row
+        for i in range(needles + 1):
+            pos.append((x0 + (i + 0.5) * wd, 0.5 * length, z))           # top row, half a width along
+        top = base + needles + 1
+        for i in range(needles):
+            # (the apex first: Moeller-Trumbore's two edges are then the two long, almost parallel ones)
+            idx.append((top + i, base + i + 1, base + i))                # needle pointing up
+            idx.append((base + i + 1, top + i, top + i + 1))             # needle pointing down
+    # the mesh is stored turned by a very small rotation about an arbitrary axis and shifted: no component of any
+    # edge is zero or a round number, yet the needles' boxes stay thin along the view; the instance turns it back
+    # ... after a turn within the sheet's own plane, which leaves the boxes as thin but makes the needles' long edges
+    # oblique to the axes: the cross products of Moeller-Trumbore then subtract products of nearly equal size
+    R = _quat_matrix(quat_axis_angle_np((0.3, -0.8, 0.52), skew_deg)) @ _quat_matrix(quat_axis_angle_np((0, 0, 1), inplane_deg))
+    shift = np.array([3.1, -1.7, 2.3])
+    pos = (np.asarray(pos, dtype=np.float64) @ R.T + shift).astype(np.float32)
+    idx = np.asarray(idx, dtype=np.int32)
+    nrm = np.tile((R @ np.array([0.0, 0.0, -1.0])).astype(np.float32), (len(pos), 1))
+    sys_ = H.BuildAccelerateStructureSystem()
+    comb = sys_.BakeBLAS(H.Mesh(pos, nrm, idx), int(rs.randint(0, 2)))
+    quad = sys_.BakeBLAS(H.Mesh.quad())
+    span = needles * wd
+    # world = Rx(tilt) * R^-1 * (p - shift)
+    Rt = _quat_matrix(quat_axis_angle_np((1, 0, 0), tilt_deg)) @ R.T
+    m = np.eye(4)
+    m[:3, :3] = Rt
+    m[:3, 3] = -Rt @ shift
+    sys_.AddEntity(comb, m.T.astype(np.float32).reshape(16), albedo=(0.7, 0.7, 0.7), specular=(0.1, 0.1, 0.1))
+    sys_.AddEntity(quad, H.trs((0, -2.0, 0), _rot_x(90), (40, 40, 1)), albedo=(0.8, 0.8, 0.8), specular=(0.04, 0.04, 0.04))
+    sys_.AddEntity(quad, H.trs((0, 6.0, 0), _rot_x(-90), (6, 6, 1)), albedo=(0, 0, 0), specular=(0, 0, 0), emission=(3, 3, 3))
+    buf = sys_.OnUpdate()
+    sys_.close()
+    # the camera looks along -z at the sheets' front faces from close enough that the comb fills the frame
+    dist = 0.6 * span / np.tan(np.radians(20.0))
+    frame = look_at_camera((0.0, 0.05 * length, -dist), (0.0, 0.0, 0.0), 40.0, w, h)
+    return buf, frame, procedural_sky()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of several builds on the GPU box: tools/ab_variants.sh lib1.so lib2.so ...   (under raytracing_amd/lib/)
-# For each variant after the first: the kernels-against-oracle parity tests, then the three bench scenes.
+# For each variant after the first: the kernels-against-oracle parity tests, then the bench line (mesh, spheres, instanced, REF frames).
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
 : > gpurun_out/ab_variants.txt
@@ -12,4 +12,3 @@ for lib in "$@"; do
   first=0
 done
 tools/ab.sh -- "$@" | tee -a gpurun_out/ab_variants.txt
-tools/ab.sh --workload instanced -- "$@" | tee -a gpurun_out/ab_variants.txt
