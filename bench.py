@@ -255,6 +255,58 @@ def secondary_workloads(rt, frame, out, args, dev, kernel_name, roofline):
     return others
 
 
+def frame_equals_one_gpu(rt, frame, W, Hh, out, args, dev, rank, world, multi, inproc, buf, sky):
+    """Before the timed region of a run over several GPUs: the same frame at 4 samples per pixel rendered sharded
+    (exactly as the timed steps shard it) and whole on one GPU; with tile sharding the two must be the same bits.
+    Returns the fields the JSON line reports (on rank 0; None elsewhere)."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import backend, distributed as D, types as T
+    kw = dict(mode=T.MODE_PT, spp=4 * max(1, world if multi else args.gpus), max_bounces=args.bounces, seed=args.seed)
+    many = torch.zeros_like(out)
+    if inproc:
+        rt.Execute(frame, W, Hh, out_rgba=many, flags=T.FLAG_SHARD_SAMPLES if args.sharding == "samples" else 0, **kw)
+        mi = rt.MultiInfo()
+        extra = {"rccl_ranks": mi["rccl_ranks"], "exchange_ms": mi["exchange_ms"]}
+    elif args.sharding == "tiles":
+        rt.Execute(frame, W, Hh, out_rgba=many, **D.tile_shard_kwargs(rank, world), **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        D.combine_tiles([many])
+        torch.cuda.synchronize()
+        extra = {"rccl_ranks": dist.get_world_size(), "exchange_ms": (time.perf_counter() - t0) * 1e3}
+    else:
+        per = kw["spp"] // world
+        k2 = dict(kw, spp=per, sample_offset=rank * per, flags=T.FLAG_OUTPUT_SUM)
+        rt.Execute(frame, W, Hh, out_rgba=many, **k2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        D.combine_samples(many)
+        torch.cuda.synchronize()
+        extra = {"rccl_ranks": dist.get_world_size(), "exchange_ms": (time.perf_counter() - t0) * 1e3}
+    if rank != 0:
+        return None
+    if inproc:
+        single = backend.RayTracingPass(0)
+        single.SetScene(buf)
+        single.SetSkyBox(sky)
+    else:
+        single = rt
+    one = torch.zeros_like(out)
+    single.Execute(frame, W, Hh, out_rgba=one, **kw)
+    torch.cuda.synchronize()
+    if inproc:
+        single.Dispose()
+    a, b = many.cpu().numpy(), one.cpu().numpy()
+    same_bits = hashlib.sha256(a.tobytes()).hexdigest() == hashlib.sha256(b.tobytes()).hexdigest()
+    rel = float((np.abs(a - b) / np.maximum(np.abs(b), 1e-3)).max())
+    extra.update({"image_equal_to_one_gpu": bool(same_bits) if args.sharding == "tiles" else bool(rel < 1e-5),
+                  "image_check": (f"{kw['spp']} spp of the timed frame, {args.sharding}-sharded against one GPU: "
+                                  + ("same bits" if same_bits else f"largest relative difference {rel:.3g}"))})
+    return extra
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,6 +398,9 @@ def main():
         if multi:
             dist.barrier()
 
+    check = None
+    if multi or inproc:
+        check = frame_equals_one_gpu(rt, frame, W, Hh, out, args, dev, rank, world, multi, inproc, buf, sky)
     elapsed, acc, last = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, barrier)
     rays = acc["rays"]
     if multi:
@@ -395,6 +450,11 @@ def main():
                        "samples_per_s": W * Hh * spp / (elapsed / n)},
             "roofline": roofline, "cpu_baseline": base,
         }
+        if check is not None:
+            result.update(check)
+        if inproc:
+            mi = rt.MultiInfo()
+            result.update({"rccl_ranks": mi["rccl_ranks"], "exchange_ms": mi["exchange_ms"], "exchange_note": mi["note"] or None})
         if others:
             result["other_workloads"] = others
         print(json.dumps(result), flush=True)

@@ -102,3 +102,72 @@ def test_multi_context_rejects_bad_device_lists():
         backend.RayTracingPass(devices=[])
     with pytest.raises(backend.BackendError, match="device 99"):
         backend.RayTracingPass(devices=[0, 99])
+
+
+def _distinct_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif("_distinct_devices() < 2", reason="needs two GPUs: RCCL takes one communicator rank per device")
+@pytest.mark.parametrize("sharding", ["tiles", "samples"])
+def test_rccl_carries_the_exchange_between_distinct_gpus(gpu_pass, scene, sharding):
+    """On a node with several GPUs the gather (ncclSend / ncclRecv) and the reduction (ncclReduce) run inside
+    the library: one rank per device, and the frame equals the one-GPU frame (bit for bit with tile sharding,
+    to the rounding of the per-pixel sum with sample sharding)."""
+    import torch
+    from raytracing_amd import backend
+    buf, frame, sky = scene
+    w, h = 333, 190
+    n = min(_distinct_devices(), 8)
+    gpu_pass.SetScene(buf)
+    gpu_pass.SetSkyBox(sky)
+    m = backend.RayTracingPass(devices=list(range(n)))
+    try:
+        info = m.MultiInfo()
+        assert info["devices"] == n and info["rccl_ranks"] == n, info
+        m.SetScene(buf)
+        m.SetSkyBox(sky)
+        kw = dict(mode=T.MODE_PT, spp=2 * n, max_bounces=5, seed=33)
+        one = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, **kw)
+        many = m.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, flags=T.FLAG_SHARD_SAMPLES if sharding == "samples" else 0, **kw)
+        assert m.MultiInfo()["rccl_ranks"] == n, m.MultiInfo()        # (no run-time fall-back happened)
+        assert _same(one["ids"], many["ids"]) and _same(one["t"], many["t"]) and one["rays"] == many["rays"]
+        if sharding == "tiles":
+            assert _same(one["rgba"], many["rgba"])
+        else:
+            scale = np.maximum(np.abs(one["rgba"]), 1e-3)
+            assert (np.abs(one["rgba"] - many["rgba"]) / scale).max() < 1e-5      # fp32 sum of 2n terms in another order
+    finally:
+        m.Dispose()
+
+
+def test_exchange_falls_back_to_peer_copies_when_rccl_fails_at_run_time(gpu_pass, scene, monkeypatch):
+    """A failing RCCL call must not lose the frame: the communicators are dropped, peer copies carry this and
+    every later exchange, and the context says so.  (RTAMD_RCCL_FAIL makes the library treat its first RCCL call
+    of the exchange as failed; with one GPU the rehearsal context has no communicator and takes the peer-copy
+    path from the start, which is the path the fall-back ends in.)"""
+    import torch
+    from raytracing_amd import backend
+    buf, frame, sky = scene
+    w, h = 333, 190
+    gpu_pass.SetScene(buf)
+    gpu_pass.SetSkyBox(sky)
+    n = _distinct_devices()
+    devices = list(range(min(n, 4))) if n >= 2 else [0, 0]
+    monkeypatch.setenv("RTAMD_RCCL_FAIL", "1")
+    m = backend.RayTracingPass(devices=devices)
+    try:
+        m.SetScene(buf)
+        m.SetSkyBox(sky)
+        for flags in (0, T.FLAG_SHARD_SAMPLES):
+            kw = dict(mode=T.MODE_PT, spp=4, max_bounces=4, seed=2)
+            one = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, **kw)
+            many = m.Execute(frame, w, h, out_rgba=True, out_prim_id=True, flags=flags, **kw)
+            assert _same(one["ids"], many["ids"]) and one["rays"] == many["rays"]
+            if flags == 0:
+                assert _same(one["rgba"], many["rgba"])
+            info = m.MultiInfo()
+            assert info["rccl_ranks"] == 0 and "peer copies" in info["note"], info
+    finally:
+        m.Dispose()
