@@ -41,6 +41,12 @@ struct FastScene {
     int32_t tlasRoot;            // index of the TLAS root in nodes
     // nodes kept in LDS by every workgroup: [0, hotTlas) and [blasBase, blasBase + hotBlas)
     int32_t hotTlas, blasBase, hotBlas;
+    // Every box bound of the caller's trees, sorted, per tree and axis (REF mode and the primary-id pass settle rays
+    // with a zero direction component against it, see planesClear in kernel_fast.h): planeRange[(tree * 3 + axis) * 2]
+    // = first value and count in `planes`; tree = BLAS index, or planeTlas for the top-level tree; count < 0: no table
+    const float* planes;
+    const int32_t* planeRange;
+    int32_t planeTlas;
     int32_t* stackSpill;         // overflow of the LDS traversal stacks: [spillMax][threads of the grid]
     int32_t spillMax;            // overflow entries per lane (0: none, a deeper stack hands its pixel over at once)
 };

@@ -40,10 +40,13 @@
 //   FShade  96 B  three rows of LocalToWorld, albedo, specular, emission
 #pragma once
 
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernel_common.h"
@@ -80,6 +83,13 @@ struct FastSceneHost {
     int tlasReserve = 0, nTlasNodes = 0;
     std::vector<int32_t> hSlotOf;      // per instance (visiting order): TLAS node << 2 | leaf slot
     DBuf<int32_t> slotOf, dBlasRoot;
+    // box bounds of the caller's trees, sorted and distinct, per tree and axis (FastScene::planes); the top-level
+    // tree's part is rewritten by every object refresh behind the bottom-level part
+    std::vector<float> hPlanes;
+    std::vector<int32_t> hPlaneRange;
+    size_t blasPlaneCount = 0;
+    DBuf<float> planes;
+    DBuf<int32_t> planeRange;
     DBuf<int32_t> guardBlas;           // per BLAS: marked by the culling guard (RT_GUARD_FACTOR); cleared by a scene upload, kept over object refreshes
     int nBlasOfScene = 0;
     std::vector<int32_t> hSuper;
@@ -98,7 +108,7 @@ struct FastSceneHost {
 
     void release() {
         nodes.release(); inst.release(); shade.release(); tris.release(); nrms.release(); triOrig.release();
-        superTiles.release(); stackSpill.release(); stats.release(); slotOf.release(); dBlasRoot.release(); guardBlas.release();
+        superTiles.release(); stackSpill.release(); stats.release(); slotOf.release(); dBlasRoot.release(); guardBlas.release(); planes.release(); planeRange.release();
         tlasDeviceDestroy(tlasBuilder);
         tlasBuilder = nullptr;
     }
@@ -156,6 +166,24 @@ struct FastSceneHost {
         std::memcpy(pair, out, sizeof(out));
     }
 
+    // sort every set and drop repeated values (NaN bounds cannot equal a ray's origin and are dropped too)
+    static void sortPlaneSets(std::vector<std::vector<float>>& sets) {
+        auto one = [](std::vector<float>& v) {
+            v.erase(std::remove_if(v.begin(), v.end(), [](float x) { return x != x; }), v.end());
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+        };
+        const size_t nThreads = sets.size() < 6 ? sets.size() : 6;
+        std::vector<std::thread> th;
+        std::atomic<size_t> next{0};
+        auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < sets.size();) one(sets[k]); };
+        try {
+            for (size_t t = 1; t < nThreads; t++) th.emplace_back(work);
+        } catch (...) { }      // (fewer threads: the caller's thread does the rest)
+        work();
+        for (auto& t : th) t.join();
+    }
+
     // Re-build every BLAS.  Inputs were validated by the caller (indices in range, every
     // node reachable at most once).  From the caller's tree come, per triangle, its leaf-slot
     // box and its rank in the reference's visiting order (children pushed 0..3, popped last
@@ -174,6 +202,7 @@ struct FastSceneHost {
         std::vector<int32_t> orig;     // by global rank: the caller's triangle index
         blasRoot.assign(nBlas, 0);
         maxDepth = 0;
+        std::vector<std::vector<float>> planeSets((size_t)nBlas * 3);
         for (int b = 0; b < nBlas; b++) {
             const rtamd_node* nodes_ = blas + blasOffsets[b];
             const rtamd_int3* tri = tris_ + triOffsets[b];
@@ -187,6 +216,12 @@ struct FastSceneHost {
                 int ni = st.back();
                 st.pop_back();
                 const rtamd_node& n = nodes_[ni];
+                for (int i = 0; i < 4; i++)
+                    if (n.Flags == 0 ? n.Data[i] != 0 : n.Data[i] != -1) {
+                        planeSets[(size_t)b * 3 + 0].push_back(n.Lx[i]); planeSets[(size_t)b * 3 + 0].push_back(n.Hx[i]);
+                        planeSets[(size_t)b * 3 + 1].push_back(n.Ly[i]); planeSets[(size_t)b * 3 + 1].push_back(n.Hy[i]);
+                        planeSets[(size_t)b * 3 + 2].push_back(n.Lz[i]); planeSets[(size_t)b * 3 + 2].push_back(n.Hz[i]);
+                    }
                 if (n.Flags == 0) {
                     for (int i = 0; i < 4; i++) if (n.Data[i] != 0) st.push_back(n.Data[i]);
                     continue;
@@ -299,6 +334,20 @@ struct FastSceneHost {
         blasUploaded = false;
         hipError_t e;
         nBlasOfScene = nBlas;
+        {
+            // the tables of box bounds: sorted and distinct per BLAS and axis (the sorting on host threads, one set each)
+            sortPlaneSets(planeSets);
+            hPlanes.clear();
+            hPlaneRange.assign(((size_t)nBlas + 1) * 6, 0);
+            for (size_t k = 0; k < planeSets.size(); k++) {
+                hPlaneRange[2 * k] = (int32_t)hPlanes.size();
+                hPlaneRange[2 * k + 1] = (int32_t)planeSets[k].size();
+                hPlanes.insert(hPlanes.end(), planeSets[k].begin(), planeSets[k].end());
+            }
+            blasPlaneCount = hPlanes.size();
+            planesUploaded = false;
+            if (blasPlaneCount >= ((size_t)1 << 31)) { err = "too many box bounds for the table of planes"; return hipSuccess; }
+        }
         if ((e = guardBlas.ensure((size_t)nBlas)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(guardBlas.p, 0, (size_t)nBlas * sizeof(int32_t), stream)) != hipSuccess) return e;
         if ((e = tris.put(ft, stream)) != hipSuccess) return e;
@@ -332,6 +381,36 @@ struct FastSceneHost {
                 if (n.Data[i] != -1) hSlotOf.push_back((int32_t)((uint32_t)ni << 2 | (uint32_t)i));
         }
         if (hSlotOf.empty()) { err = "TLAS references no object"; return hipSuccess; }
+        {
+            // box bounds of the caller's top-level tree (a large tree, which the device rebuilds in well under a
+            // millisecond, gets no table: its zero-component rays go to the reference-order kernel as before)
+            const size_t tl = (size_t)nBlasOfScene * 6;
+            hPlanes.resize(blasPlaneCount);
+            if (hSlotOf.size() > (size_t)kTlasDeviceMin) {
+                for (int ax = 0; ax < 3; ax++) { hPlaneRange[tl + 2 * ax] = 0; hPlaneRange[tl + 2 * ax + 1] = -1; }
+            } else {
+                std::vector<std::vector<float>> sets(3);
+                std::vector<int32_t> walk;
+                walk.push_back(1);
+                while (!walk.empty()) {
+                    const rtamd_node& n = tlas[walk.back()];
+                    walk.pop_back();
+                    for (int i = 0; i < 4; i++)
+                        if (n.Flags == 0 ? n.Data[i] != 0 : n.Data[i] != -1) {
+                            sets[0].push_back(n.Lx[i]); sets[0].push_back(n.Hx[i]);
+                            sets[1].push_back(n.Ly[i]); sets[1].push_back(n.Hy[i]);
+                            sets[2].push_back(n.Lz[i]); sets[2].push_back(n.Hz[i]);
+                            if (n.Flags == 0) walk.push_back(n.Data[i]);
+                        }
+                }
+                sortPlaneSets(sets);
+                for (int ax = 0; ax < 3; ax++) {
+                    hPlaneRange[tl + 2 * ax] = (int32_t)hPlanes.size();
+                    hPlaneRange[tl + 2 * ax + 1] = (int32_t)sets[ax].size();
+                    hPlanes.insert(hPlanes.end(), sets[ax].begin(), sets[ax].end());
+                }
+            }
+        }
         if (hSlotOf.size() >= kInstanceBit || (unsigned)nTlas >= (1u << 29)) { err = "too many instances"; return hipSuccess; }
         nInst = (int)hSlotOf.size();
         tlasRoot = 0;
@@ -364,6 +443,16 @@ struct FastSceneHost {
             if ((e = dBlasRoot.put(blasRoot, stream)) != hipSuccess) return e;
             blasUploaded = true;
         } else if (!onDevice && (e = hipMemcpyAsync(nodes.p, hNodes.data(), (size_t)nTlasNodes * sizeof(WNode), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+        {
+            // the bottom-level part of the table goes up with the scene, the top-level part with every refresh
+            const bool whole = planes.n < hPlanes.size() || !planesUploaded;
+            if ((e = planes.ensure(hPlanes.size() + (whole ? hPlanes.size() / 8 + 1024 : 0))) != hipSuccess) return e;
+            const size_t from = whole ? 0 : blasPlaneCount;
+            if (hPlanes.size() > from &&
+                (e = hipMemcpyAsync(planes.p + from, hPlanes.data() + from, (hPlanes.size() - from) * sizeof(float), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+            if ((e = planeRange.put(hPlaneRange, stream)) != hipSuccess) return e;
+            planesUploaded = true;
+        }
         if ((e = slotOf.put(hSlotOf, stream)) != hipSuccess) return e;
         if ((e = inst.ensure((size_t)nInst)) != hipSuccess || (e = shade.ensure((size_t)nInst)) != hipSuccess) return e;
         if ((e = tlasPackInstances(dTlas, dObjects, slotOf.p, dBlasRoot.p, guardBlas.p, nInst, inst.p, shade.p, stream)) != hipSuccess) return e;
@@ -381,6 +470,7 @@ struct FastSceneHost {
     static constexpr int kTlasDeviceMin = 4096;   // instances from which the device build is used when the caller does not choose
     int tlasDepth = 0;
     bool blasUploaded = false;
+    bool planesUploaded = false;
 };
 
 // ------------------------------------------------------------------ kernel ---
@@ -492,6 +582,30 @@ __device__ __forceinline__ void cswap(float& da, int32_t& ca, float& db, int32_t
 // so small that 1/d overflows) can turn a slab product into 0 * inf = NaN.
 __device__ __forceinline__ bool rayDegenerate(const Ray& r) {
     return !(__builtin_fabsf(r.invDir.x) < RT_INF) || !(__builtin_fabsf(r.invDir.y) < RT_INF) || !(__builtin_fabsf(r.invDir.z) < RT_INF);
+}
+
+// A ray with a zero direction component (a non-finite reciprocal) is traversed like any other as long as its origin
+// does not lie exactly on a box bound of that axis: every slab product of the axis is then -inf or +inf, which min
+// and max treat like any number, in the caller's trees and in the rebuilt ones alike.  Only a bound equal to the
+// origin's coordinate gives 0 * inf = NaN, which min / max drop, and then the caller's own inner boxes decide
+// (RayTracingShader.compute:233-263).  The tables hold every bound of the caller's tree `tree` (a BLAS index, or
+// sc.planeTlas), sorted: one binary search per degenerate axis.  False: hand the ray to the reference-order kernel.
+__device__ __forceinline__ bool planesClear(const FastScene& sc, int tree, const Ray& r) {
+    const float o[3] = {r.origin.x, r.origin.y, r.origin.z}, inv[3] = {r.invDir.x, r.invDir.y, r.invDir.z};
+    bool clear = true;
+#pragma unroll 1
+    for (int ax = 0; ax < 3; ax++) {
+        if (__builtin_fabsf(inv[ax]) < RT_INF) continue;
+        const int first = sc.planeRange[(tree * 3 + ax) * 2], count = sc.planeRange[(tree * 3 + ax) * 2 + 1];
+        if (count < 0 || !(o[ax] == o[ax])) { clear = false; continue; }
+        int lo = 0, hi = count;        // first value >= o[ax]
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (sc.planes[first + mid] < o[ax]) lo = mid + 1; else hi = mid;
+        }
+        if (lo < count && sc.planes[first + lo] == o[ax]) clear = false;
+    }
+    return clear;
 }
 
 // Position, shading normal and material of the closest hit (.compute:329-339).
@@ -725,7 +839,10 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(rtamd_frame
                 node = sc.tlasRoot; sp = 0; instSp = kNoInstance; curInst = -1; spilled = 0;
                 trav = true;
                 pixRays++;
-                if (rayDegenerate(next)) RT_REDO();
+                // (coherent rays -- REF mode, the primary-id pass -- meet exact zeros as a matter of course: the centre
+                // column and row of every un-jittered frame of an axis-aligned camera; they are settled against the tables
+                // of box bounds.  Path-traced rays practically never do, and go to the reference-order kernel.)
+                if (rayDegenerate(next) && (MODE == kModePt || !planesClear(sc, sc.planeTlas, next))) RT_REDO();
             }
         }
         if (__ballot(trav) == 0ull) break;   // nobody got a ray: every lane is out of work
@@ -734,7 +851,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(rtamd_frame
 #define RT_CAN_REFILL (!trav && !(noMoreWork && !pixelActive && !pathActive))
 #define RT_TWO_SIDED (DIEL && insideGlass)
 #define RT_KEEP_HIT(t_, u_, v_, tri_) do { best.u = (u_); best.v = (v_); } while (0)
+#define RT_LOCAL_RAY_UNSETTLED(rank_) (rayDegenerate(cur) && (MODE == kModePt || !planesClear(sc, __float_as_int(sc.inst[rank_].pad.x), cur)))
 #include "traverse_body.inc"
+#undef RT_LOCAL_RAY_UNSETTLED
 #undef RT_KEEP_HIT
 #undef RT_TWO_SIDED
 #undef RT_CAN_REFILL
@@ -847,6 +966,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
     sc.nodes = fs.nodes.p; sc.inst = fs.inst.p; sc.shade = fs.shade.p;
     sc.tris = fs.tris.p; sc.nrms = fs.nrms.p; sc.triOrig = fs.triOrig.p; sc.nSuperTiles = (int)fs.hSuper.size();
     sc.tlasRoot = fs.tlasRoot;
+    sc.planes = fs.planes.p; sc.planeRange = fs.planeRange.p; sc.planeTlas = fs.nBlasOfScene;
     if (lent) {
         sc.superTiles = lent->superTiles;
         // (the kernel indexes the area by gridDim.x: whole chunks per lane of the grid actually launched)

@@ -480,7 +480,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(rtamd_frame
 #define RT_TWO_SIDED (DIEL && twoSided)
         // the closest hit's t, u, v, triangle go straight to the slot's LDS entry (two registers less to carry)
 #define RT_KEEP_HIT(t_, u_, v_, tri_) do { ldsHit[wave][slot] = make_float4((t_), (u_), (v_), __int_as_float(tri_)); } while (0)
+#define RT_LOCAL_RAY_UNSETTLED(rank_) rayDegenerate(cur)
 #include "traverse_body.inc"
+#undef RT_LOCAL_RAY_UNSETTLED
 #undef RT_KEEP_HIT
 #undef RT_TWO_SIDED
 #undef RT_CAN_REFILL
@@ -665,6 +667,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     sc.nodes = fs.nodes.p; sc.inst = fs.inst.p; sc.shade = fs.shade.p;
     sc.tris = fs.tris.p; sc.nrms = fs.nrms.p; sc.triOrig = fs.triOrig.p; sc.superTiles = fs.superTiles.p; sc.nSuperTiles = (int)fs.hSuper.size();
     sc.tlasRoot = fs.tlasRoot;
+    sc.planes = fs.planes.p; sc.planeRange = fs.planeRange.p; sc.planeTlas = fs.nBlasOfScene;
     if ((e = fs.stackSpill.ensure((size_t)kSpillMax * (size_t)(numCU * cfg.blocksPerCU) * kBlockThreads)) != hipSuccess) return e;
     sc.stackSpill = fs.stackSpill.p;
     sc.spillMax = kSpillMax;
