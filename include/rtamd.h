@@ -300,11 +300,14 @@ int rtamd_last_handover_stats(const rtamd_ctx* ctx, float* handover_ms, int32_t*
  * reference's triangle as long as no triangle's own boxes are entered, as computed, more than
  * 2^-8 (relative) behind its own computed hit distance -- rounding error, a few ulps on ordinary
  * meshes, larger on extreme slivers and huge coordinates.  Every hit the kernels compute is
- * checked against a quarter of that slack (2^-10): such a ray goes to the reference-order kernel
- * and the hit's mesh is marked; from then on (until the next rtamd_scene_upload) every ray
- * entering an instance of a marked mesh goes to the reference-order kernel, and the frame in
- * which it happened is rendered a second time before rtamd_render returns (not a frame with
- * RTAMD_FLAG_ACCUMULATE, whose samples are in the running sum already).
+ * checked against a quarter of that slack (2^-10): such a ray goes to the reference-order
+ * kernel, which counts the hits of this kind it computes, per mesh.  A mesh that shows at
+ * least four of them in a frame and more than one per million ray segments (a single one in a
+ * billion rays is the tail of ordinary rounding) is marked: from then on (until the next
+ * rtamd_scene_upload) every ray entering an instance of a marked mesh goes to the
+ * reference-order kernel, and the frame in which it happened is rendered a second time before
+ * rtamd_render returns (not a frame with RTAMD_FLAG_ACCUMULATE, whose samples are in the
+ * running sum already).
  *   hits_near_slack  such hits in the last rtamd_render call (first pass)
  *   demoted_meshes   meshes (BLAS) of the scene currently handled in reference order
  *   rerendered       1 when the last call rendered its frame twice

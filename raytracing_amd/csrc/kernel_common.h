@@ -19,7 +19,7 @@ struct RefScene {
     // The guard of the production kernels' distance culling (RT_GUARD_FACTOR, kernel_fast.h), kept by the
     // reference-order kernels, which trace what the production kernels hand over: *guardCount counts the hits
     // whose own boxes are entered, as computed, more than 2^-10 behind the hit's computed distance,
-    // guardBlas[b] is set for every BLAS b such a hit lay in.  Either may be null.
+    // guardBlas[b] those that lay in BLAS b.  Both null in a render the caller asked to be in reference order.
     int32_t* guardCount;
     int32_t* guardBlas;
 };

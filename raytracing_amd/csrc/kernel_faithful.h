@@ -102,7 +102,7 @@ __device__ __forceinline__ void refIntersectBlas(const RefScene& sc, const Ray& 
                         // not part of the reference: the guard of the production kernels' distance culling (RT_GUARD_FACTOR)
                         if (fmax_(refSlabNear(node, i, localRay), instNear) > t * RT_GUARD_FACTOR) {
                             if (sc.guardCount) atomicAdd(sc.guardCount, 1);
-                            if (sc.guardBlas) atomicOr(sc.guardBlas + blasIndex, 1);
+                            if (sc.guardBlas) atomicAdd(sc.guardBlas + blasIndex, 1);
                         }
                         if (t > 0 && t < best.t) {
                             cnt.hits++;

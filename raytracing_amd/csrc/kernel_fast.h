@@ -90,7 +90,11 @@ struct FastSceneHost {
     size_t blasPlaneCount = 0;
     DBuf<float> planes;
     DBuf<int32_t> planeRange;
-    DBuf<int32_t> guardBlas;           // per BLAS: marked by the culling guard (RT_GUARD_FACTOR); cleared by a scene upload, kept over object refreshes
+    // The culling guard (RT_GUARD_FACTOR): guardBlas counts, per BLAS, the hits the reference-order kernels saw come
+    // near the slack since the host last looked; blasDemoted holds the host's verdict per BLAS (1: every ray entering
+    // an instance of it goes to the reference-order kernel), cleared by a scene upload, kept over object refreshes.
+    DBuf<int32_t> guardBlas, blasDemoted;
+    std::vector<int32_t> hDemoted;
     int nBlasOfScene = 0;
     std::vector<int32_t> hSuper;
     int nInst = 0;
@@ -108,7 +112,7 @@ struct FastSceneHost {
 
     void release() {
         nodes.release(); inst.release(); shade.release(); tris.release(); nrms.release(); triOrig.release();
-        superTiles.release(); stackSpill.release(); stats.release(); slotOf.release(); dBlasRoot.release(); guardBlas.release(); planes.release(); planeRange.release();
+        superTiles.release(); stackSpill.release(); stats.release(); slotOf.release(); dBlasRoot.release(); guardBlas.release(); blasDemoted.release(); planes.release(); planeRange.release();
         tlasDeviceDestroy(tlasBuilder);
         tlasBuilder = nullptr;
     }
@@ -348,8 +352,10 @@ struct FastSceneHost {
             planesUploaded = false;
             if (blasPlaneCount >= ((size_t)1 << 31)) { err = "too many box bounds for the table of planes"; return hipSuccess; }
         }
-        if ((e = guardBlas.ensure((size_t)nBlas)) != hipSuccess) return e;
+        hDemoted.assign((size_t)nBlas, 0);
+        if ((e = guardBlas.ensure((size_t)nBlas)) != hipSuccess || (e = blasDemoted.ensure((size_t)nBlas)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(guardBlas.p, 0, (size_t)nBlas * sizeof(int32_t), stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(blasDemoted.p, 0, (size_t)nBlas * sizeof(int32_t), stream)) != hipSuccess) return e;
         if ((e = tris.put(ft, stream)) != hipSuccess) return e;
         if ((e = nrms.put(fn, stream)) != hipSuccess) return e;
         if ((e = triOrig.put(orig, stream)) != hipSuccess) return e;
@@ -455,17 +461,19 @@ struct FastSceneHost {
         }
         if ((e = slotOf.put(hSlotOf, stream)) != hipSuccess) return e;
         if ((e = inst.ensure((size_t)nInst)) != hipSuccess || (e = shade.ensure((size_t)nInst)) != hipSuccess) return e;
-        if ((e = tlasPackInstances(dTlas, dObjects, slotOf.p, dBlasRoot.p, guardBlas.p, nInst, inst.p, shade.p, stream)) != hipSuccess) return e;
+        if ((e = tlasPackInstances(dTlas, dObjects, slotOf.p, dBlasRoot.p, blasDemoted.p, nInst, inst.p, shade.p, stream)) != hipSuccess) return e;
         if (onDevice) {
             if (!tlasBuilder && !(tlasBuilder = tlasDeviceCreate())) return hipErrorOutOfMemory;
             return tlasDeviceBuild(tlasBuilder, inst.p, nInst, nodes.p, tlasReserve, stream, &nTlasNodes, &tlasDepth);
         }
         return hipSuccess;
     }
-    // The culling guard marked a mesh during a render: the per-instance records are written again, now with
-    // kDemotedBit on every instance of a marked mesh (the tree over the instances does not change).
+    // The host marked another mesh (hDemoted) after a render: the verdicts go up and the per-instance records are
+    // written again, now with kDemotedBit on every instance of a marked mesh (the tree over the instances stays).
     hipError_t applyDemotions(const rtamd_node* dTlas, const rtamd_object_property* dObjects, hipStream_t stream) {
-        return tlasPackInstances(dTlas, dObjects, slotOf.p, dBlasRoot.p, guardBlas.p, nInst, inst.p, shade.p, stream);
+        hipError_t e = hipMemcpyAsync(blasDemoted.p, hDemoted.data(), hDemoted.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+        return tlasPackInstances(dTlas, dObjects, slotOf.p, dBlasRoot.p, blasDemoted.p, nInst, inst.p, shade.p, stream);
     }
     static constexpr int kTlasDeviceMin = 4096;   // instances from which the device build is used when the caller does not choose
     int tlasDepth = 0;

@@ -597,7 +597,8 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
     rt::RefScene rsc;
     rsc.tlas = c->tlas.p; rsc.blasOffsets = c->blasOffsets.p; rsc.blas = c->blas.p; rsc.vtxOffsets = c->vtxOffsets.p;
     rsc.verts = c->verts.p; rsc.triOffsets = c->triOffsets.p; rsc.tris = c->tris.p; rsc.objects = c->objects.p;
-    rsc.guardCount = (int32_t*)(ctrl + kNaOffGuardCount); rsc.guardBlas = c->fast.guardBlas.p;
+    rsc.guardCount = faithful ? nullptr : (int32_t*)(ctrl + kNaOffGuardCount);
+    rsc.guardBlas = faithful ? nullptr : c->fast.guardBlas.p;
     HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
     if (a.tileW > 0 && a.tileH > 0) {
         if (faithful) {
@@ -687,23 +688,28 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
     c->lastHandoverMs = handoverMs;
     {
         // The culling guard (RT_GUARD_FACTOR, kernel_fast.h).  The rays it fired on were handed over one by one and are
-        // exact; but a mesh that comes this close to the slack may also have hidden a hit from the kernel unseen.  Every
-        // instance of the marked meshes is switched to the reference-order kernel (until the next scene upload) and
-        // the frame is rendered once more.  A frame that adds to the running sum is not (its samples are in the sum
-        // already): there the switch takes effect from the next frame on.
+        // exact.  A single such hit in a billion rays is the tail of ordinary rounding (a hit a hair's breadth from the
+        // ray's origin) and changes nothing else; a mesh that shows them at a rate -- at least kGuardMinHits in the frame
+        // and more than one per million ray segments -- may also have hidden a hit from the kernel unseen: every instance
+        // of it is switched to the reference-order kernel (until the next scene upload) and the frame is rendered once
+        // more.  A frame that adds to the running sum is not rendered again (its samples are in the sum already): there
+        // the switch takes effect from the next frame on.
         int32_t guardHits = 0;
         std::memcpy(&guardHits, c->hostCtrl + kNaOffGuardCount, sizeof(guardHits));
         if (!afterGuard) { c->lastGuardHits = guardHits; c->lastGuardRerendered = 0; }
         if (guardHits > 0 && !afterGuard && !faithful) {
-            // (on a scene with marked meshes the reference-order kernel sees such hits in every frame: only a newly
-            // marked mesh changes anything)
-            std::vector<int32_t> marked((size_t)c->fast.nBlasOfScene, 0);
-            HIP_TRY(c, hipMemcpyAsync(marked.data(), c->fast.guardBlas.p, marked.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            constexpr int32_t kGuardMinHits = 4;
+            std::vector<int32_t> seen((size_t)c->fast.nBlasOfScene, 0);
+            HIP_TRY(c, hipMemcpyAsync(seen.data(), c->fast.guardBlas.p, seen.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->fast.guardBlas.p, 0, seen.size() * sizeof(int32_t), c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            int32_t nowMarked = 0;
-            for (int32_t m : marked) nowMarked += m != 0;
-            const bool newlyMarked = nowMarked > c->demotedMeshes;
-            c->demotedMeshes = nowMarked;
+            bool newlyMarked = false;
+            for (size_t b = 0; b < seen.size(); b++)
+                if (!c->fast.hDemoted[b] && seen[b] >= kGuardMinHits && (double)seen[b] > 1e-6 * (double)hr[0]) {
+                    c->fast.hDemoted[b] = 1;
+                    c->demotedMeshes++;
+                    newlyMarked = true;
+                }
             if (newlyMarked) HIP_TRY(c, c->fast.applyDemotions(c->tlas.p, c->objects.p, c->stream));
             if (newlyMarked && getenv("RTAMD_VERBOSE"))
                 fprintf(stderr, "[rtamd] culling guard: %d hits within a quarter of the slack; %d of %d meshes now go to the reference-order kernel\n", guardHits,

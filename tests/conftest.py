@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# torch brings its own copy of the HIP runtime: imported before librtamd.so is loaded, both use that one copy;
+# the other way round torch finds a second runtime in the process and sees no GPU.  Some GPU tests hand torch
+# tensors to the library, so every run of any subset of the tests imports torch first.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
