@@ -267,6 +267,25 @@ int rtamd_render_noalloc(rtamd_ctx* ctx, const rtamd_frame_cbuffer* frame,
                          const rtamd_ext_params* ext, int32_t width, int32_t height,
                          float* out_rgba_device, int32_t* out_prim_id_device);
 
+/* rtamd_render in two halves, for a host that renders frame after frame (the reference's pass
+ * runs once per camera per frame, RayTracingPass.cs:62-109, and its DispatchCompute (:101) does
+ * not block either: the command buffer is executed later): rtamd_render_begin queues the frame
+ * and returns, rtamd_render_wait completes the oldest frame begun and returns its status; the
+ * rtamd_last_* statistics then describe that frame.  At most two frames are in flight, so the
+ * second frame's kernels fill the GPU while the first one's last paths finish, are summed and
+ * the host looks at its counters.  Same image as rtamd_render, bit for bit (one exception:
+ * with RTAMD_FLAG_ACCUMULATE a pixel that needed the per-pixel hand-over pass may receive two
+ * frames' sums in the other order).  Limits (RTAMD_ERR_INVALID_ARG): outputs in device memory,
+ * a separate output buffer per frame in flight; no RTAMD_FLAG_COUNTERS /
+ * RTAMD_FLAG_REFERENCE_ORDER; a path-traced frame must fit one batch of paths
+ * (width * height * spp up to 2^29 on a 288 GB part); not on a context over several GPUs.
+ * While a frame is in flight, rtamd_render, scene / sky uploads, rtamd_accum_reset and
+ * rtamd_set_stream are refused. */
+int rtamd_render_begin(rtamd_ctx* ctx, const rtamd_frame_cbuffer* frame,
+                       const rtamd_ext_params* ext, int32_t width, int32_t height,
+                       float* out_rgba_device, int32_t* out_prim_id_device);
+int rtamd_render_wait(rtamd_ctx* ctx);
+
 /* Drop the running sum used by RTAMD_FLAG_ACCUMULATE. */
 int rtamd_accum_reset(rtamd_ctx* ctx);
 

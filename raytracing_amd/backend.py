@@ -15,7 +15,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "lib
 _lib = None
 
 EXPORTS = ["rtamd_ctx_create", "rtamd_ctx_create_multi", "rtamd_multi_info", "rtamd_multi_exchange_note", "rtamd_ctx_destroy", "rtamd_last_error_string", "rtamd_scene_upload",
-           "rtamd_scene_refresh_objects", "rtamd_sky_upload", "rtamd_render", "rtamd_render_noalloc", "rtamd_accum_reset",
+           "rtamd_scene_refresh_objects", "rtamd_sky_upload", "rtamd_render", "rtamd_render_noalloc", "rtamd_render_begin", "rtamd_render_wait", "rtamd_accum_reset",
            "rtamd_set_stream", "rtamd_set_tlas_build", "rtamd_tlas_info", "rtamd_last_render_stats", "rtamd_last_trace_kernel_ms", "rtamd_last_handover_stats", "rtamd_last_guard_stats", "rtamd_composite_add", "rtamd_present", "rtamd_version"]
 
 
@@ -49,6 +49,8 @@ def lib():
         L.rtamd_sky_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.rtamd_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(T.ExtParams), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.rtamd_render_noalloc.argtypes = L.rtamd_render.argtypes
+        L.rtamd_render_begin.argtypes = L.rtamd_render.argtypes
+        L.rtamd_render_wait.argtypes = [C.c_void_p]
         L.rtamd_accum_reset.argtypes = [C.c_void_p]
         L.rtamd_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.rtamd_set_tlas_build.argtypes = [C.c_void_p, C.c_int32]
@@ -223,6 +225,26 @@ class RayTracingPass:
         self._check(rc)
         return dict(rgba=out_rgba, ids=out_prim_id, t=out_t, counters=cnt.as_dict() if counters else None,
                     kernel_ms=ms.value, rays=int(rays.value), trace_ms=tms.value, handover_ms=hms.value, handover_pixels=int(hpix.value))
+
+    def ExecuteBegin(self, frame, width, height, out_rgba=None, out_prim_id=None, out_t=None, **ext_kw):
+        """rtamd_render_begin: queue a frame and return before it is complete (device-memory outputs; at most two
+        frames in flight).  ExecuteWait completes the oldest frame begun and returns its statistics."""
+        e = self.ext(**ext_kw)
+        if out_t is not None:
+            e.out_t = _ptr(out_t)
+        frame = np.ascontiguousarray(frame, dtype=T.FRAME)
+        self._check(lib().rtamd_render_begin(self._ctx, _ptr(frame), C.byref(e), width, height, _ptr(out_rgba), _ptr(out_prim_id)))
+
+    def ExecuteWait(self):
+        rc = lib().rtamd_render_wait(self._ctx)
+        ms, rays = C.c_float(0), C.c_uint64(0)
+        lib().rtamd_last_render_stats(self._ctx, C.byref(ms), C.byref(rays))
+        hms, hpix = C.c_float(0), C.c_int32(0)
+        lib().rtamd_last_handover_stats(self._ctx, C.byref(hms), C.byref(hpix))
+        tms = C.c_float(0)
+        lib().rtamd_last_trace_kernel_ms(self._ctx, C.byref(tms))
+        self._check(rc)
+        return dict(kernel_ms=ms.value, rays=int(rays.value), trace_ms=tms.value, handover_ms=hms.value, handover_pixels=int(hpix.value))
 
     def ExecuteDefault(self, frame, width, height, out_rgba, out_prim_id=None):
         """The plain reference dispatch: no extension block (REF mode)."""

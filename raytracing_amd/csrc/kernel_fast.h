@@ -96,7 +96,21 @@ struct FastSceneHost {
     DBuf<int32_t> guardBlas, blasDemoted;
     std::vector<int32_t> hDemoted;
     int nBlasOfScene = 0;
-    std::vector<int32_t> hSuper;
+    std::vector<int32_t> hSuper, hSuperOnDevice;      // the tile list of this launch / the one superTiles holds
+    // The tile list goes up only when it differs from the one on the device: consecutive frames of one size share it,
+    // and a frame still in flight (rtamd_render_begin) may be reading it.
+    hipError_t putSuperTiles(hipStream_t stream) {
+        if (superTiles.p && hSuper == hSuperOnDevice) return hipSuccess;
+        if (asyncInFlight > 0) {
+            // (a frame in flight reads the old list: wait for it before the list changes)
+            hipError_t se = hipDeviceSynchronize();
+            if (se != hipSuccess) return se;
+        }
+        hipError_t e = superTiles.put(hSuper, stream);
+        if (e == hipSuccess) hSuperOnDevice = hSuper;
+        return e;
+    }
+    int asyncInFlight = 0;             // frames begun with rtamd_render_begin and not yet waited for
     int nInst = 0;
     int tlasRoot = 0;
     int maxDepth = 0;
@@ -955,7 +969,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
     if (lent) {
         if (fs.hSuper.size() > (size_t)lent->superCap) return hipErrorInvalidValue;
         e = hipMemcpyAsync(lent->superTiles, fs.hSuper.data(), fs.hSuper.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-    } else e = fs.superTiles.put(fs.hSuper, stream);
+    } else e = fs.putSuperTiles(stream);
     if (e != hipSuccess) return e;
 
     const int numCU = fs.numCU;

@@ -568,6 +568,18 @@ struct PoolHost {
     // device time of the kPool launches of the last render: one pair of events per launch
     std::vector<hipEvent_t> evBegin, evEnd;
     int nTimed = 0;
+    // frames that return before they are complete (rtamd_render_begin): frame k uses half k & 1 of the sample buffer
+    // and of the path list, and a pair of timing events of its own
+    hipEvent_t asyncBegin[2] = {nullptr, nullptr}, asyncEnd[2] = {nullptr, nullptr};
+    bool halfSummedOnce[2] = {false, false};
+    hipError_t asyncEvents() {
+        hipError_t err = hipSuccess;
+        for (int k = 0; k < 2 && err == hipSuccess; k++) {
+            if (!asyncBegin[k]) err = hipEventCreate(&asyncBegin[k]);
+            if (err == hipSuccess && !asyncEnd[k]) err = hipEventCreate(&asyncEnd[k]);
+        }
+        return err;
+    }
     void release() {
         recs.release(); sampleL.release(); runSum.release(); pathList.release();
         for (hipEvent_t ev : evBegin) (void)hipEventDestroy(ev);
@@ -575,6 +587,10 @@ struct PoolHost {
         evBegin.clear(); evEnd.clear();
         nTimed = 0;
         for (int k = 0; k < 2; k++) {
+            if (asyncBegin[k]) (void)hipEventDestroy(asyncBegin[k]);
+            if (asyncEnd[k]) (void)hipEventDestroy(asyncEnd[k]);
+            asyncBegin[k] = asyncEnd[k] = nullptr;
+            halfSummedOnce[k] = false;
             if (evTraced[k]) (void)hipEventDestroy(evTraced[k]);
             if (evSummed[k]) (void)hipEventDestroy(evSummed[k]);
             evTraced[k] = evSummed[k] = nullptr;
@@ -626,9 +642,15 @@ inline size_t poolMaxPaths(const FastSceneHost& fs) {
 
 // PT-mode render of the pixels selected by `a` (radiance only: the identity of the primary
 // hit comes from kFast<kModePrimary>, launched here first when asked for).
+// asyncSlot >= 0 (rtamd_render_begin): the frame must fit one batch; it uses half `asyncSlot` of the sample buffer and
+// of the path list, its hand-over paths and its summation always run on the second stream behind the trace, and
+// *lastStream receives the stream the frame's last kernel was queued on.  A frame of the other kind that does not fit
+// one batch returns hipErrorNotSupported here before anything is launched.
 inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, const RenderArgs& a, hipStream_t stream,
-                             const RefScene& rsc, int32_t* pathCountA, int32_t* pathCountB, int32_t* pathTotal) {
-    ph.nTimed = 0;
+                             const RefScene& rsc, int32_t* pathCountA, int32_t* pathCountB, int32_t* pathTotal,
+                             int asyncSlot = -1, hipStream_t* lastStream = nullptr) {
+    if (asyncSlot < 0) ph.nTimed = 0;
+    if (lastStream) *lastStream = stream;
     int tilesX = (a.width + 31) / 32;
     fs.hSuper.clear();
     int sx0 = a.tileX / 32, sx1 = (a.tileX + a.tileW - 1) / 32, sy0 = a.tileY / 32, sy1 = (a.tileY + a.tileH - 1) / 32;
@@ -639,7 +661,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             fs.hSuper.push_back(sx | (sy << 16));
         }
     if (fs.hSuper.empty()) return hipSuccess;
-    hipError_t e = fs.superTiles.put(fs.hSuper, stream);
+    hipError_t e = fs.putSuperTiles(stream);
     if (e != hipSuccess) return e;
 
     const int numCU = fs.numCU;
@@ -709,9 +731,10 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         samplesPerBatch = cap / workPerChunk;
         if (samplesPerBatch < 1) samplesPerBatch = 1;
         if (samplesPerBatch > (size_t)a.spp) samplesPerBatch = (size_t)a.spp;
-        // (two halves when the frame takes more than one batch)
+        // (two halves when the frame takes more than one batch, or is one of two frames in flight)
         const bool several = workPerChunk < fs.hSuper.size() * 1024 || samplesPerBatch < (size_t)a.spp;
-        e = ph.sampleL.ensure(workPerChunk * samplesPerBatch * (several ? 2 : 1));
+        if (asyncSlot >= 0 && several) return hipErrorNotSupported;
+        e = ph.sampleL.ensure(workPerChunk * samplesPerBatch * (several || asyncSlot >= 0 ? 2 : 1));
         if (e == hipSuccess) e = ph.runSum.ensure(workPerChunk);
         if (e == hipSuccess) break;
         if (e != hipErrorOutOfMemory || cap <= ((size_t)1 << 20)) return e;
@@ -722,13 +745,14 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         if ((e = fs.stats.ensure(25)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(fs.stats.p, 0, 25 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
     }
-    const bool overlap = (workPerChunk < fs.hSuper.size() * 1024 || samplesPerBatch < (size_t)a.spp) && !getenv("RTAMD_POOL_NO_OVERLAP");
+    const bool overlap = asyncSlot >= 0 || ((workPerChunk < fs.hSuper.size() * 1024 || samplesPerBatch < (size_t)a.spp) && !getenv("RTAMD_POOL_NO_OVERLAP"));
     if (overlap && (e = ph.sideStream()) != hipSuccess) return e;
+    if (asyncSlot >= 0 && (e = ph.asyncEvents()) != hipSuccess) return e;
     int batchNo = 0;
     for (size_t t0 = 0; t0 < fs.hSuper.size(); t0 += tilesPerChunk) {
         const size_t nt = fs.hSuper.size() - t0 < tilesPerChunk ? fs.hSuper.size() - t0 : tilesPerChunk;
         for (int s0 = 0; s0 < a.spp; s0 += (int)samplesPerBatch, batchNo++) {
-            const int half = overlap ? (batchNo & 1) : 0;
+            const int half = asyncSlot >= 0 ? asyncSlot : (overlap ? (batchNo & 1) : 0);
             PoolBatch b;
             b.recs = ph.recs.p; b.sampleL = ph.sampleL.p + (size_t)half * workPerChunk * samplesPerBatch; b.runSum = ph.runSum.p;
             b.next = a.rayCount + 1;
@@ -741,8 +765,8 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             if (const char* pc = getenv("RTAMD_POOL_PATH_CAP")) { int v = atoi(pc); if (v >= 0 && v < b.pathCap) b.pathCap = v; }      // (tests: a short list)
             hotRanges(big ? kPoolHotNodesBig : kPoolHotNodes, b.hotTlas, b.hotBlas);
             const unsigned long long total = (unsigned long long)b.nWork * (unsigned long long)b.nSamples;
-            // this half of the buffers is free once the batch before the last has been added up
-            if (overlap && batchNo >= 2 && (e = hipStreamWaitEvent(stream, ph.evSummed[half], 0)) != hipSuccess) return e;
+            // this half of the buffers is free once the batch before the last (the frame before the last) has been added up
+            if (overlap && (asyncSlot >= 0 ? ph.halfSummedOnce[half] : batchNo >= 2) && (e = hipStreamWaitEvent(stream, ph.evSummed[half], 0)) != hipSuccess) return e;
             if ((e = hipMemsetAsync(a.rayCount + 1, 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
             long long blocksNeeded = (long long)((total + kBlockThreads - 1) / kBlockThreads);
             int grid = blocksNeeded < gridMax ? (int)blocksNeeded : gridMax;
@@ -753,8 +777,9 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
                 if (const char* cv = getenv("RTAMD_POOL_CHUNK")) { int v = atoi(cv); if (v >= 1 && v <= 65536) b.chunk = v; }
                 if ((uint32_t)b.chunk > b.nWork) b.chunk = (int)b.nWork;
             }
-            if ((e = ph.eventsFor(ph.nTimed)) != hipSuccess) return e;
-            if ((e = hipEventRecord(ph.evBegin[ph.nTimed], stream)) != hipSuccess) return e;
+            if (asyncSlot >= 0) e = hipEventRecord(ph.asyncBegin[asyncSlot], stream);
+            else if ((e = ph.eventsFor(ph.nTimed)) == hipSuccess) e = hipEventRecord(ph.evBegin[ph.nTimed], stream);
+            if (e != hipSuccess) return e;
 #define RT_LAUNCH_POOL(S_, D_, B_, stats_) hipLaunchKernelGGL((kPool<S_, D_, B_>), dim3(grid), dim3(kBlockThreads), 0, stream, a.cb, sc, sky, a, b, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, poolSlots, stats_)
             if (a.flags & RTAMD_FLAG_DIELECTRICS) RT_LAUNCH_POOL(false, true, false, (unsigned long long*)nullptr);
             else if (cfg.stats && big) RT_LAUNCH_POOL(true, false, true, fs.stats.p);
@@ -762,7 +787,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             else if (big) RT_LAUNCH_POOL(false, false, true, (unsigned long long*)nullptr);
             else RT_LAUNCH_POOL(false, false, false, (unsigned long long*)nullptr);
 #undef RT_LAUNCH_POOL
-            if ((e = hipEventRecord(ph.evEnd[ph.nTimed++], stream)) != hipSuccess) return e;
+            if ((e = hipEventRecord(asyncSlot >= 0 ? ph.asyncEnd[asyncSlot] : ph.evEnd[ph.nTimed++], stream)) != hipSuccess) return e;
             // the paths the launch could not settle (a few hundred per frame; blocks without a path end at once), then
             // the summation: behind the launch on the second stream when more batches follow on this one
             hipStream_t after = stream;
@@ -776,8 +801,10 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
             hipLaunchKernelGGL(kPoolSum, dim3((b.nWork + 255) / 256), dim3(256), 0, after, sc, a, b);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if (overlap && (e = hipEventRecord(ph.evSummed[half], ph.side)) != hipSuccess) return e;
+            if (asyncSlot >= 0) { ph.halfSummedOnce[half] = true; if (lastStream) *lastStream = ph.side; }
         }
     }
+    if (asyncSlot >= 0) return hipSuccess;       // (the caller's stream goes straight on to the next frame; rtamd_render_wait waits for the second stream)
     // the caller's stream goes on when the last batch has been added up (the batches before it were added up earlier
     // on the same second stream)
     if (overlap && batchNo > 0 && (e = hipStreamWaitEvent(stream, ph.evSummed[(batchNo - 1) & 1], 0)) != hipSuccess) return e;

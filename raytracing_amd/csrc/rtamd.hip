@@ -151,6 +151,26 @@ struct rtamd_ctx {
     float lastKernelMs = 0.f, lastHandoverMs = 0.f, lastTraceMs = 0.f;
     uint64_t lastRays = 0;
 
+    // Frames that return before they are complete (rtamd_render_begin / rtamd_render_wait): up to two in flight,
+    // each with a working set of its own (the control block, the hand-over mask and list) and what
+    // rtamd_render_wait needs to finish the frame.
+    struct FrameSlot {
+        DevBuf<unsigned char> ctrl;
+        unsigned char* hostCtrl = nullptr;       // pinned
+        DevBuf<uint32_t> redoMask;
+        DevBuf<int32_t> redoList;
+        hipEvent_t evStart = nullptr, evStop = nullptr, evDone = nullptr;
+        rt::RenderArgs a;
+        rtamd_frame_cbuffer frame;
+        rtamd_ext_params e;
+        int32_t width = 0, height = 0;
+        float* outRgba = nullptr;
+        int32_t* outIds = nullptr;
+        bool usedPool = false;
+    };
+    FrameSlot slots[2];
+    int asyncBegun = 0, asyncInFlight = 0;        // frames begun so far / not yet waited for (0 .. 2)
+
     // A context over several GPUs (rtamd_ctx_create_multi) owns one ordinary context per device and
     // nothing else on the GPUs; subs[0] is the device the finished frame is assembled on.
     std::vector<rtamd_ctx*> subs;
@@ -168,6 +188,12 @@ int fail(rtamd_ctx* c, int code, const std::string& msg) {
     if (c) c->error = msg; else g_createError = msg;
     return code;
 }
+// Scene, sky and running-sum changes and blocking renders are for a context with no frame in flight.
+#define NO_FRAME_IN_FLIGHT(c, what)                                                                                                  \
+    do {                                                                                                                             \
+        if ((c)->asyncInFlight > 0)                                                                                                  \
+            return fail(c, RTAMD_ERR_INVALID_ARG, std::string(what) + ": frames begun with rtamd_render_begin are in flight, call rtamd_render_wait first"); \
+    } while (0)
 int failHip(rtamd_ctx* c, hipError_t e, const char* what) {
     return fail(c, e == hipErrorOutOfMemory ? RTAMD_ERR_OUT_OF_MEMORY : RTAMD_ERR_HIP,
                 std::string(what) + ": " + hipGetErrorString(e));
@@ -316,6 +342,14 @@ int rtamd_ctx_destroy(rtamd_ctx* c) {
     c->verts.release(); c->tris.release(); c->objects.release(); c->sky.release(); c->accum.release();
     c->tmp8.release(); c->outRgba.release(); c->outIds.release(); c->outT.release(); c->ctrl.release();
     c->redoMask.release(); c->redoList.release(); c->redoSamples.release();
+    if (c->pool.side) (void)hipStreamSynchronize(c->pool.side);
+    for (rtamd_ctx::FrameSlot& S : c->slots) {
+        S.ctrl.release(); S.redoMask.release(); S.redoList.release();
+        if (S.hostCtrl) (void)hipHostFree(S.hostCtrl);
+        if (S.evStart) (void)hipEventDestroy(S.evStart);
+        if (S.evStop) (void)hipEventDestroy(S.evStop);
+        if (S.evDone) (void)hipEventDestroy(S.evDone);
+    }
     if (c->hostCtrl) (void)hipHostFree(c->hostCtrl);
     c->fast.release();
     c->pool.release();
@@ -328,6 +362,7 @@ int rtamd_ctx_destroy(rtamd_ctx* c) {
 
 int rtamd_set_stream(rtamd_ctx* c, void* s) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
+    NO_FRAME_IN_FLIGHT(c, "rtamd_set_stream");
     if (!c->subs.empty()) return fail(c, RTAMD_ERR_INVALID_ARG, "a context over several GPUs runs every device on a stream of its own");
     c->stream = s ? (hipStream_t)s : c->ownStream;
     return RTAMD_OK;
@@ -385,6 +420,7 @@ int rtamd_scene_upload(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas, cons
         c->haveScene = rc == RTAMD_OK;
         return rc;
     }
+    NO_FRAME_IN_FLIGHT(c, "rtamd_scene_upload");
     if (!tlas || !blasOffsets || !blas || !vtxOffsets || !verts || !triOffsets || !tris || !objects)
         return fail(c, RTAMD_ERR_INVALID_ARG, "NULL scene buffer");
     if (nTlas < 2 || nBlasNodes < 2 || nVerts < 1 || nTris < 1 || nBlas < 1 || nObjects < 1)
@@ -442,6 +478,7 @@ int rtamd_scene_refresh_objects(rtamd_ctx* c, const rtamd_node* tlas, int32_t nT
     return guarded(c, [&]() -> int {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (!c->subs.empty()) return multi::forEach(c, [&](rtamd_ctx* sub) { return rtamd_scene_refresh_objects(sub, tlas, nTlas, objects, nObjects); });
+    NO_FRAME_IN_FLIGHT(c, "rtamd_scene_refresh_objects");
     if (!c->haveScene) return fail(c, RTAMD_ERR_NO_SCENE, "refresh before a scene upload");
     if (!tlas || !objects || nTlas < 2) return fail(c, RTAMD_ERR_INVALID_ARG, "NULL / empty buffer");
     if (nObjects != c->nObjects) return fail(c, RTAMD_ERR_INVALID_ARG, "object count differs from the uploaded scene");
@@ -457,6 +494,7 @@ int rtamd_sky_upload(rtamd_ctx* c, const float* rgba, int32_t w, int32_t h) {
     return guarded(c, [&]() -> int {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (!c->subs.empty()) return multi::forEach(c, [&](rtamd_ctx* sub) { return rtamd_sky_upload(sub, rgba, w, h); });
+    NO_FRAME_IN_FLIGHT(c, "rtamd_sky_upload");
     HIP_TRY(c, hipSetDevice(c->device));
     if (!rgba || w <= 0 || h <= 0) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -473,6 +511,7 @@ int rtamd_sky_upload(rtamd_ctx* c, const float* rgba, int32_t w, int32_t h) {
 int rtamd_accum_reset(rtamd_ctx* c) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (!c->subs.empty()) return multi::forEach(c, [&](rtamd_ctx* sub) { return rtamd_accum_reset(sub); });
+    NO_FRAME_IN_FLIGHT(c, "rtamd_accum_reset");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->accum.p) HIP_TRY(c, hipMemsetAsync(c->accum.p, 0, c->accum.n * sizeof(float4), c->stream));
     return RTAMD_OK;
@@ -488,6 +527,7 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
     if (!frame) return fail(c, RTAMD_ERR_INVALID_ARG, "frame is NULL");
     if (width <= 0 || height <= 0 || width > (1 << 20) || height > (1 << 20) || (int64_t)width * height > (1ll << 30)) return fail(c, RTAMD_ERR_INVALID_ARG, "bad image size");
     if (!c->haveScene) return fail(c, RTAMD_ERR_NO_SCENE, "render before a scene upload");
+    if (!afterGuard) NO_FRAME_IN_FLIGHT(c, "rtamd_render");
     rtamd_ext_params e;
     std::memset(&e, 0, sizeof(e));
     e.struct_size = sizeof(e); e.mode = RTAMD_MODE_REF; e.spp = 1;
@@ -1094,6 +1134,217 @@ int rtamd_render_noalloc(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const r
     return guarded(c, [&]() -> int {
     if (c && !c->subs.empty()) return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_noalloc: not available on a context over several GPUs (the exchange buffers are sized to the frame)");
     return renderCore(c, frame, ext, width, height, out_rgba_device, out_prim_id_device, true);
+    });
+}
+
+// ---- frames that return before they are complete ----------------------------------------------------------------
+// rtamd_render_begin queues a frame and returns; rtamd_render_wait completes the oldest frame begun.  With two frames
+// in flight the second frame's trace kernel fills the chip while the first one's last paths drain, and the first
+// frame's hand-over paths and summation run on the context's second stream beside it (path tracing), and the host's
+// part of a frame (read-back, the decision about a hand-over pass) overlaps the next frame's kernels (REF mode).
+int rtamd_render_begin(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtamd_ext_params* ext, int32_t width, int32_t height,
+                       float* out_rgba_device, int32_t* out_prim_id_device) {
+    return guarded(c, [&]() -> int {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->subs.empty()) return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_begin: not available on a context over several GPUs");
+    if (!frame) return fail(c, RTAMD_ERR_INVALID_ARG, "frame is NULL");
+    if (width <= 0 || height <= 0 || width > (1 << 20) || height > (1 << 20) || (int64_t)width * height > (1ll << 30)) return fail(c, RTAMD_ERR_INVALID_ARG, "bad image size");
+    if (!c->haveScene) return fail(c, RTAMD_ERR_NO_SCENE, "render before a scene upload");
+    if (c->asyncInFlight >= 2) return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_begin: two frames are in flight already, call rtamd_render_wait first");
+    rtamd_ext_params e;
+    std::memset(&e, 0, sizeof(e));
+    e.struct_size = sizeof(e); e.mode = RTAMD_MODE_REF; e.spp = 1;
+    if (ext) {
+        if (ext->struct_size != sizeof(rtamd_ext_params)) return fail(c, RTAMD_ERR_INVALID_ARG, "ext.struct_size mismatch");
+        e = *ext;
+    }
+    if (e.mode != RTAMD_MODE_REF && e.mode != RTAMD_MODE_PT) return fail(c, RTAMD_ERR_INVALID_ARG, "unknown mode");
+    if (e.mode == RTAMD_MODE_PT && (e.spp < 1 || e.max_bounces < 0 || e.sample_offset < 0))
+        return fail(c, RTAMD_ERR_INVALID_ARG, "PT mode needs spp >= 1, max_bounces >= 0, sample_offset >= 0");
+    if (e.shard_count > 1 && (e.shard_rank < 0 || e.shard_rank >= e.shard_count)) return fail(c, RTAMD_ERR_INVALID_ARG, "shard_rank out of range");
+    if (e.flags & (RTAMD_FLAG_COUNTERS | RTAMD_FLAG_REFERENCE_ORDER)) return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_begin: counters and reference order are for rtamd_render");
+    if ((out_rgba_device && !isDevicePointer(out_rgba_device)) || (out_prim_id_device && !isDevicePointer(out_prim_id_device)) || (e.out_t && !isDevicePointer(e.out_t)))
+        return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_begin: outputs must be device memory");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)width * height;
+    rtamd_ctx::FrameSlot& S = c->slots[c->asyncBegun & 1];
+    if (!S.evDone) {
+        HIP_TRY(c, hipEventCreate(&S.evStart));
+        HIP_TRY(c, hipEventCreate(&S.evStop));
+        HIP_TRY(c, hipEventCreateWithFlags(&S.evDone, hipEventDisableTiming));
+        HIP_TRY(c, S.ctrl.alloc(kCtrlBytes));
+        HIP_TRY(c, hipHostMalloc((void**)&S.hostCtrl, kCtrlBytes, hipHostMallocDefault));
+    }
+    const size_t maskWords = (npix + 31) / 32;
+    HIP_TRY(c, S.redoMask.alloc(maskWords));
+    HIP_TRY(c, S.redoList.alloc(npix));
+    unsigned char* const ctrl = S.ctrl.p;
+
+    rt::RenderArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.cb = *frame;
+    a.width = width; a.height = height;
+    a.mode = e.mode; a.spp = e.mode == RTAMD_MODE_PT ? e.spp : 1; a.maxBounces = e.max_bounces;
+    a.seedHi = (uint32_t)(e.seed >> 32); a.seedLo = (uint32_t)e.seed;
+    a.sampleOffset = e.sample_offset;
+    a.tileX = 0; a.tileY = 0; a.tileW = width; a.tileH = height;
+    if (e.tile_w > 0 && e.tile_h > 0) {
+        int x0 = e.tile_x < 0 ? 0 : e.tile_x, y0 = e.tile_y < 0 ? 0 : e.tile_y;
+        int x1 = e.tile_x + e.tile_w > width ? width : e.tile_x + e.tile_w;
+        int y1 = e.tile_y + e.tile_h > height ? height : e.tile_y + e.tile_h;
+        a.tileX = x0; a.tileY = y0; a.tileW = x1 > x0 ? x1 - x0 : 0; a.tileH = y1 > y0 ? y1 - y0 : 0;
+    }
+    a.shardRank = e.shard_rank; a.shardCount = e.shard_count;
+    a.flags = e.flags;
+    a.outRgba = (float4*)out_rgba_device; a.outIds = out_prim_id_device; a.outT = e.out_t;
+    if (e.mode == RTAMD_MODE_PT && (e.flags & RTAMD_FLAG_ACCUMULATE)) {
+        if (c->accumW != width || c->accumH != height || !c->accum.p) {
+            if (c->asyncInFlight > 0) return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_begin: the running sum changes size while a frame is in flight");
+            HIP_TRY(c, c->accum.alloc(npix));
+            HIP_TRY(c, hipMemsetAsync(c->accum.p, 0, npix * sizeof(float4), c->stream));
+            c->accumW = width; c->accumH = height;
+        }
+        a.accum = c->accum.p;
+    }
+    a.counters = nullptr;
+    a.rayCount = (unsigned long long*)(ctrl + kNaOffRayCount);
+    a.errorFlag = (int32_t*)(ctrl + kNaOffErrorFlag);
+    a.redoMask = S.redoMask.p; a.redoList = S.redoList.p; a.redoCap = (int32_t)npix;
+    a.redoCount = (int32_t*)(ctrl + kNaOffRedoCount);
+
+    rt::Sky sky;
+    sky.texels = c->sky.p; sky.w = c->skyW; sky.h = c->skyH;
+    sky.invW = c->skyW > 0 ? 1.0f / (float)c->skyW : 0.f; sky.invH = c->skyH > 0 ? 1.0f / (float)c->skyH : 0.f;
+    rt::RefScene rsc;
+    rsc.tlas = c->tlas.p; rsc.blasOffsets = c->blasOffsets.p; rsc.blas = c->blas.p; rsc.vtxOffsets = c->vtxOffsets.p;
+    rsc.verts = c->verts.p; rsc.triOffsets = c->triOffsets.p; rsc.tris = c->tris.p; rsc.objects = c->objects.p;
+    rsc.guardCount = (int32_t*)(ctrl + kNaOffGuardCount); rsc.guardBlas = c->fast.guardBlas.p;
+
+    HIP_TRY(c, hipMemsetAsync(a.redoMask, 0, maskWords * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(ctrl, 0, kCtrlBytes, c->stream));
+    HIP_TRY(c, hipEventRecord(S.evStart, c->stream));
+    hipStream_t last = c->stream;
+    S.usedPool = false;
+    c->fast.asyncInFlight = c->asyncInFlight;
+    if (a.tileW > 0 && a.tileH > 0) {
+        S.usedPool = a.mode == RTAMD_MODE_PT && rt::fastLaunchConfig().pool;
+        hipError_t le = S.usedPool ? rt::launchPool(c->fast, c->pool, sky, a, c->stream, rsc, (int32_t*)(ctrl + kNaOffPathCount), (int32_t*)(ctrl + kNaOffPathCount + 8),
+                                                    (int32_t*)(ctrl + kNaOffPathCount + 4), c->asyncBegun & 1, &last)
+                                   : rt::launchFast(c->fast, sky, a, c->stream, nullptr);
+        if (le == hipErrorNotSupported) return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_begin: the frame does not fit one batch of paths; render it with rtamd_render");
+        if (le != hipSuccess) return failHip(c, le, "production kernel launch");
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipEventRecord(S.evStop, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(S.hostCtrl, ctrl, kCtrlUsed, hipMemcpyDeviceToHost, last));
+    HIP_TRY(c, hipEventRecord(S.evDone, last));
+    S.a = a; S.frame = *frame; S.e = e; S.width = width; S.height = height; S.outRgba = out_rgba_device; S.outIds = out_prim_id_device;
+    c->asyncBegun++;
+    c->asyncInFlight++;
+    c->fast.asyncInFlight = c->asyncInFlight;
+    return RTAMD_OK;
+    });
+}
+
+int rtamd_render_wait(rtamd_ctx* c) {
+    return guarded(c, [&]() -> int {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (c->asyncInFlight <= 0) return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_wait: no frame in flight");
+    HIP_TRY(c, hipSetDevice(c->device));
+    rtamd_ctx::FrameSlot& S = c->slots[(c->asyncBegun - c->asyncInFlight) & 1];
+    auto done = [&]() { c->asyncInFlight--; c->fast.asyncInFlight = c->asyncInFlight; };
+    hipError_t we = hipEventSynchronize(S.evDone);
+    if (we != hipSuccess) { done(); return failHip(c, we, "waiting for the frame"); }
+    const rt::RenderArgs& a = S.a;
+    int32_t redo = 0;
+    std::memcpy(&redo, S.hostCtrl + kNaOffRedoCount, sizeof(redo));
+    float ms = 0.f, handoverMs = 0.f;
+    (void)hipEventElapsedTime(&ms, S.evStart, S.evStop);
+    if (S.usedPool) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, c->pool.asyncBegin[(c->asyncBegun - c->asyncInFlight) & 1], c->pool.asyncEnd[(c->asyncBegun - c->asyncInFlight) & 1]) == hipSuccess) c->lastTraceMs = t;
+    } else c->lastTraceMs = ms;
+    unsigned char* const ctrl = S.ctrl.p;
+    if (redo > 0) {
+        // pixels the production kernel handed over whole: the reference-order kernel renders exactly those, on the
+        // caller's stream (behind whatever the next frame has queued there already)
+        if (redo > a.redoCap) redo = a.redoCap;
+        rt::Sky sky;
+        sky.texels = c->sky.p; sky.w = c->skyW; sky.h = c->skyH;
+        sky.invW = c->skyW > 0 ? 1.0f / (float)c->skyW : 0.f; sky.invH = c->skyH > 0 ? 1.0f / (float)c->skyH : 0.f;
+        rt::RefScene rsc;
+        rsc.tlas = c->tlas.p; rsc.blasOffsets = c->blasOffsets.p; rsc.blas = c->blas.p; rsc.vtxOffsets = c->vtxOffsets.p;
+        rsc.verts = c->verts.p; rsc.triOffsets = c->triOffsets.p; rsc.tris = c->tris.p; rsc.objects = c->objects.p;
+        rsc.guardCount = (int32_t*)(ctrl + kNaOffGuardCount); rsc.guardBlas = c->fast.guardBlas.p;
+        auto handOver = [&]() -> int {
+            HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
+            if (a.mode == RTAMD_MODE_PT) {
+                HIP_TRY(c, c->redoSamples.alloc((size_t)redo * (size_t)a.spp));
+                const size_t n = (size_t)redo * (size_t)a.spp;
+                const int spread = listSpreadFor(n);
+                hipLaunchKernelGGL(rt::kFaithful, dim3((unsigned)(((n << spread) + 63) / 64)), dim3(64), 0, c->stream, rsc, sky, a, (const int32_t*)a.redoList, redo,
+                                   c->redoSamples.p, spread);
+                HIP_TRY(c, hipGetLastError());
+                hipLaunchKernelGGL(rt::kSumListedSamples, dim3((redo + 63) / 64), dim3(64), 0, c->stream, a, (const int32_t*)a.redoList, redo, (const float4*)c->redoSamples.p);
+            } else {
+                const int spread = listSpreadFor((size_t)redo);
+                hipLaunchKernelGGL(rt::kFaithful, dim3((unsigned)((((size_t)redo << spread) + 63) / 64)), dim3(64), 0, c->stream, rsc, sky, a, (const int32_t*)a.redoList, redo,
+                                   (float4*)nullptr, spread);
+            }
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(S.hostCtrl, ctrl, kCtrlUsed, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipEventRecord(S.evDone, c->stream));
+            HIP_TRY(c, hipEventSynchronize(S.evDone));
+            HIP_TRY(c, hipEventElapsedTime(&handoverMs, c->evStart, c->evStop));
+            return RTAMD_OK;
+        };
+        const int hrc = handOver();
+        if (hrc != RTAMD_OK) { done(); return hrc; }
+        ms += handoverMs;
+    }
+    unsigned long long hr[2];
+    int32_t herr, paths = 0, guardHits = 0;
+    std::memcpy(hr, S.hostCtrl + kNaOffRayCount, sizeof(hr));
+    std::memcpy(&herr, S.hostCtrl + kNaOffErrorFlag, sizeof(herr));
+    std::memcpy(&paths, S.hostCtrl + kNaOffPathCount + 4, sizeof(paths));
+    std::memcpy(&guardHits, S.hostCtrl + kNaOffGuardCount, sizeof(guardHits));
+    c->lastRedoPixels = redo + (S.usedPool ? paths : 0);
+    c->lastHandoverMs = handoverMs;
+    c->lastKernelMs = ms;
+    c->lastRays = hr[0];
+    c->lastGuardHits = guardHits; c->lastGuardRerendered = 0;
+    done();
+    if (guardHits > 0) {
+        // the culling guard, as in rtamd_render: a newly marked mesh means this frame is rendered again, in a blocking
+        // call, once the other frame in flight (rendered before the mark) has left the GPU; that frame's own
+        // rtamd_render_wait looks at its own hits
+        constexpr int32_t kGuardMinHits = 4;
+        std::vector<int32_t> seen((size_t)c->fast.nBlasOfScene, 0);
+        HIP_TRY(c, hipMemcpyAsync(seen.data(), c->fast.guardBlas.p, seen.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->fast.guardBlas.p, 0, seen.size() * sizeof(int32_t), c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        bool newlyMarked = false;
+        for (size_t b = 0; b < seen.size(); b++)
+            if (!c->fast.hDemoted[b] && seen[b] >= kGuardMinHits && (double)seen[b] > 1e-6 * (double)hr[0]) {
+                c->fast.hDemoted[b] = 1;
+                c->demotedMeshes++;
+                newlyMarked = true;
+            }
+        if (newlyMarked) {
+            if (c->pool.side) HIP_TRY(c, hipStreamSynchronize(c->pool.side));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, c->fast.applyDemotions(c->tlas.p, c->objects.p, c->stream));
+            if (!(S.e.mode == RTAMD_MODE_PT && (S.e.flags & RTAMD_FLAG_ACCUMULATE))) {
+                const int rc = renderCore(c, &S.frame, &S.e, S.width, S.height, S.outRgba, S.outIds, false, true);
+                c->lastGuardRerendered = 1;
+                return rc;
+            }
+        }
+    }
+    if (herr & 1) return fail(c, RTAMD_ERR_STACK_OVERFLOW, "traversal stack overflow (scene deeper than the shader's stacks allow)");
+    if (herr & 4) return fail(c, RTAMD_ERR_OUT_OF_MEMORY, "hand-over list overflow");
+    return RTAMD_OK;
     });
 }
 
