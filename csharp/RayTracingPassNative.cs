@@ -37,9 +37,18 @@ namespace Script.RayTracing
         [DllImport(Lib)] public static extern int rtamd_tlas_info(IntPtr ctx, out int nodes, out int levels, out int builtOnDevice);
         [DllImport(Lib)] public static extern int rtamd_sky_upload(IntPtr ctx, void* rgba32f, int w, int h);
         [DllImport(Lib)] public static extern int rtamd_render(IntPtr ctx, FrameCBuffer* frame, ExtParams* ext, int w, int h, void* outRgba, void* outPrimId);
-        // rtamd_render without any device allocation (outputs must be device memory): for callers under HIP graph capture or in a serving loop
+        // rtamd_render without any device allocation (outputs must be device memory): for serving loops and hosts that budget device memory themselves
         [DllImport(Lib)] public static extern int rtamd_render_noalloc(IntPtr ctx, FrameCBuffer* frame, ExtParams* ext, int w, int h, void* outRgbaDevice, void* outPrimIdDevice);
+        // rtamd_render in two halves (device-memory outputs, up to two frames in flight): begin queues the frame and returns, wait completes the oldest one
+        [DllImport(Lib)] public static extern int rtamd_render_begin(IntPtr ctx, FrameCBuffer* frame, ExtParams* ext, int w, int h, void* outRgbaDevice, void* outPrimIdDevice);
+        [DllImport(Lib)] public static extern int rtamd_render_wait(IntPtr ctx);
         [DllImport(Lib)] public static extern int rtamd_accum_reset(IntPtr ctx);
+        // the running sum of RTAMD_FLAG_ACCUMULATE frames, out and back in (stop a progressive render and continue it later)
+        [DllImport(Lib)] public static extern int rtamd_accum_download(IntPtr ctx, void* sums, int w, int h);
+        [DllImport(Lib)] public static extern int rtamd_accum_upload(IntPtr ctx, void* sums, int w, int h);
+        // the guard of the production kernels' distance culling: hits that came near its slack in the last render, meshes now handled in reference order, frame rendered twice
+        [DllImport(Lib)] public static extern int rtamd_last_guard_stats(IntPtr ctx, out int hitsNearSlack, out int demotedMeshes, out int rerendered);
+        [DllImport(Lib)] public static extern int rtamd_last_render_stats(IntPtr ctx, out float kernelMs, out ulong raySegments);
         [DllImport(Lib)] public static extern int rtamd_composite_add(IntPtr ctx, void* srcRgba32f, void* dstRgba8, int w, int h);
         [DllImport(Lib)] public static extern int rtamd_present(IntPtr ctx, void* srcRgba32f, void* dstRgba8, int w, int h, int tonemap, float exposure, float gamma);
     }

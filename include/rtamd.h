@@ -289,6 +289,14 @@ int rtamd_render_wait(rtamd_ctx* ctx);
 /* Drop the running sum used by RTAMD_FLAG_ACCUMULATE. */
 int rtamd_accum_reset(rtamd_ctx* ctx);
 
+/* The running sum itself (width*height*4 floats: rgb sums and the sample count per pixel), out
+ * to the caller and back in: with the next ext->sample_offset it is all a progressive render
+ * needs to stop and be continued later, in another process or on another GPU, with the same
+ * bits as if it had never stopped.  Either pointer may be host or device memory.  No
+ * counterpart in the reference (it keeps no history buffer, AddShader.shader:11). */
+int rtamd_accum_download(rtamd_ctx* ctx, float* sums, int32_t width, int32_t height);
+int rtamd_accum_upload(rtamd_ctx* ctx, const float* sums, int32_t width, int32_t height);
+
 /* Run kernels of this context on a caller-owned HIP stream (hipStream_t as
  * void*; NULL = the context's own stream). */
 int rtamd_set_stream(rtamd_ctx* ctx, void* hip_stream);

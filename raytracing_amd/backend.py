@@ -15,7 +15,7 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "lib
 _lib = None
 
 EXPORTS = ["rtamd_ctx_create", "rtamd_ctx_create_multi", "rtamd_multi_info", "rtamd_multi_exchange_note", "rtamd_ctx_destroy", "rtamd_last_error_string", "rtamd_scene_upload",
-           "rtamd_scene_refresh_objects", "rtamd_sky_upload", "rtamd_render", "rtamd_render_noalloc", "rtamd_render_begin", "rtamd_render_wait", "rtamd_accum_reset",
+           "rtamd_scene_refresh_objects", "rtamd_sky_upload", "rtamd_render", "rtamd_render_noalloc", "rtamd_render_begin", "rtamd_render_wait", "rtamd_accum_download", "rtamd_accum_upload", "rtamd_accum_reset",
            "rtamd_set_stream", "rtamd_set_tlas_build", "rtamd_tlas_info", "rtamd_last_render_stats", "rtamd_last_trace_kernel_ms", "rtamd_last_handover_stats", "rtamd_last_guard_stats", "rtamd_composite_add", "rtamd_present", "rtamd_version"]
 
 
@@ -51,6 +51,8 @@ def lib():
         L.rtamd_render_noalloc.argtypes = L.rtamd_render.argtypes
         L.rtamd_render_begin.argtypes = L.rtamd_render.argtypes
         L.rtamd_render_wait.argtypes = [C.c_void_p]
+        L.rtamd_accum_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.rtamd_accum_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.rtamd_accum_reset.argtypes = [C.c_void_p]
         L.rtamd_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.rtamd_set_tlas_build.argtypes = [C.c_void_p, C.c_int32]
@@ -173,6 +175,16 @@ class RayTracingPass:
         h, m, r = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         self._check(lib().rtamd_last_guard_stats(self._ctx, C.byref(h), C.byref(m), C.byref(r)))
         return {"hits_near_slack": h.value, "demoted_meshes": m.value, "rerendered": bool(r.value)}
+
+    def DownloadAccumulation(self, width, height):
+        """The running sum (h, w, 4): rgb sums and the sample count per pixel."""
+        out = np.zeros((height, width, 4), dtype=np.float32)
+        self._check(lib().rtamd_accum_download(self._ctx, _ptr(out), width, height))
+        return out
+
+    def UploadAccumulation(self, sums):
+        sums = np.ascontiguousarray(sums, dtype=np.float32)
+        self._check(lib().rtamd_accum_upload(self._ctx, _ptr(sums), sums.shape[1], sums.shape[0]))
 
     def ResetAccumulation(self):
         self._check(lib().rtamd_accum_reset(self._ctx))

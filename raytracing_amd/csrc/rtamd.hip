@@ -1348,6 +1348,37 @@ int rtamd_render_wait(rtamd_ctx* c) {
     });
 }
 
+// The running sum of RTAMD_FLAG_ACCUMULATE frames (rgb sums and the sample count per pixel) out to / in from the
+// host: what a progressive render needs to stop and go on later, together with the next sample_offset.
+int rtamd_accum_download(rtamd_ctx* c, float* sums_host, int32_t width, int32_t height) {
+    return guarded(c, [&]() -> int {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->subs.empty()) return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_accum_download: on a context over several GPUs every device keeps the sums of its own tiles");
+    NO_FRAME_IN_FLIGHT(c, "rtamd_accum_download");
+    if (!sums_host || width <= 0 || height <= 0) return fail(c, RTAMD_ERR_INVALID_ARG, "NULL buffer or bad size");
+    if (!c->accum.p || c->accumW != width || c->accumH != height) return fail(c, RTAMD_ERR_INVALID_ARG, "no running sum of this size");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(sums_host, c->accum.p, (size_t)width * height * sizeof(float4), hipMemcpyDefault, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTAMD_OK;
+    });
+}
+
+int rtamd_accum_upload(rtamd_ctx* c, const float* sums_host, int32_t width, int32_t height) {
+    return guarded(c, [&]() -> int {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->subs.empty()) return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_accum_upload: on a context over several GPUs every device keeps the sums of its own tiles");
+    NO_FRAME_IN_FLIGHT(c, "rtamd_accum_upload");
+    if (!sums_host || width <= 0 || height <= 0 || (int64_t)width * height > (1ll << 30)) return fail(c, RTAMD_ERR_INVALID_ARG, "NULL buffer or bad size");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->accum.alloc((size_t)width * height));
+    c->accumW = width; c->accumH = height;
+    HIP_TRY(c, hipMemcpyAsync(c->accum.p, sums_host, (size_t)width * height * sizeof(float4), hipMemcpyDefault, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RTAMD_OK;
+    });
+}
+
 int rtamd_last_trace_kernel_ms(const rtamd_ctx* c, float* ms) {
     if (!c || !ms) return RTAMD_ERR_INVALID_ARG;
     *ms = c->lastTraceMs;

@@ -112,6 +112,38 @@ def test_progressive_accumulation(gpu_pass, oracle, scene_few):
     gpu_pass.ResetAccumulation()
 
 
+def test_running_sum_saved_and_restored_continues_with_the_same_bits(gpu_pass, scene_few):
+    """A progressive render stopped after two frames, its running sum taken out (rtamd_accum_download), put into a
+    fresh context (rtamd_accum_upload) and continued there ends with the bits of the render that never stopped."""
+    from raytracing_amd import backend
+    buf, frame, sky = scene_few
+    w, h = 64, 36
+    gpu_pass.SetScene(buf)
+    gpu_pass.SetSkyBox(sky)
+    kw = dict(mode=T.MODE_PT, max_bounces=3, seed=5, spp=2, flags=T.FLAG_ACCUMULATE)
+    gpu_pass.ResetAccumulation()
+    for i in range(4):
+        straight = gpu_pass.Execute(frame, w, h, out_rgba=True, sample_offset=2 * i, **kw)["rgba"]
+    gpu_pass.ResetAccumulation()
+    for i in range(2):
+        gpu_pass.Execute(frame, w, h, out_rgba=True, sample_offset=2 * i, **kw)
+    saved = gpu_pass.DownloadAccumulation(w, h)
+    assert np.all(saved[..., 3] == 4.0)
+    gpu_pass.ResetAccumulation()
+    other = backend.RayTracingPass(0)
+    try:
+        other.SetScene(buf)
+        other.SetSkyBox(sky)
+        other.UploadAccumulation(saved)
+        for i in range(2, 4):
+            resumed = other.Execute(frame, w, h, out_rgba=True, sample_offset=2 * i, **kw)["rgba"]
+        assert np.array_equal(resumed, straight)
+        with pytest.raises(backend.BackendError, match="no running sum of this size"):
+            other.DownloadAccumulation(w + 1, h)
+    finally:
+        other.Dispose()
+
+
 def test_refresh_objects_moves_an_instance(gpu_pass, oracle):
     sys = H.BuildAccelerateStructureSystem()
     sph = sys.BakeBLAS(H.Mesh.uv_sphere(16, 8, 0.5))

@@ -76,10 +76,20 @@ def demangle(names):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    lib = args[0] if args else os.path.join(ROOT, "raytracing_amd", "lib", "librtamd.so")
-    out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
-    result = {"library": os.path.relpath(lib, ROOT), "targets": []}
+    argv = sys.argv[1:]
+    out_json = None
+    if "--json" in argv:
+        i = argv.index("--json")
+        out_json = argv[i + 1]
+        del argv[i:i + 2]
+    lib = argv[0] if argv else os.path.join(ROOT, "raytracing_amd", "lib", "librtamd.so")
+    sha = None
+    m = re.search(rb"rtamd [0-9.]+ gfx950 src:([0-9a-f]+)", open(lib, "rb").read())
+    if m:
+        sha = m.group(1).decode()
+    result = {"library": os.path.relpath(lib, ROOT), "kernel_source_sha": sha,
+              "limits": {"vgpr_per_simd_lane": VGPR_TOTAL, "max_waves_per_simd": MAX_WAVES, "lds_bytes_per_cu": LDS_PER_CU},
+              "targets": []}
     for triple, elf in code_objects(lib):
         ks = kernels_of(elf)
         short = demangle([k["name"] for k in ks])
