@@ -327,9 +327,10 @@ def test_4k_frame_production_kernel_equals_reference_order_kernel(gpu_pass, orac
     assert rays == fast["rays"]
 
 
-def test_fifty_million_instanced_triangles(gpu_pass):
+def test_fifty_million_instanced_triangles(gpu_pass, oracle):
     """1 250 instances of 40 000-triangle meshes (the largest configuration's scene): production
-    kernel, on a host-built and on a device-built top-level tree, against the reference-order kernel."""
+    kernel, on a host-built and on a device-built top-level tree, against the reference-order kernel
+    on every pixel and against the CPU oracle on the whole 640x360 frame (path tracing and REF mode)."""
     from raytracing_amd import scenes
     w, h = 640, 360
     buf, frame, sky = scenes.instanced_scene(w, h, instances=1250, tris_per_blas=40_000)
@@ -350,6 +351,14 @@ def test_fifty_million_instanced_triangles(gpu_pass):
         assert _same(g["rgba"], ref["rgba"]), _report("50M", g, ref)
         assert g["rays"] == ref["rays"]
     assert (ref["ids"][..., 0] > 0).mean() > 0.2
+    o = oracle.render(buf, frame, w, h, sky=sky, nthreads=16, **kw)
+    g = results[0]
+    assert _same(g["ids"], o["ids"]) and _same(g["t"], o["t"]), _report("50M vs oracle", g, o)
+    assert _same(g["rgba"], o["rgba"]), _report("50M vs oracle", g, o)
+    assert g["rays"] == o["counters"]["rays"]
+    gr = gpu_pass.Execute(frame, w, h, out_rgba=True, out_prim_id=True, out_t=True, mode=T.MODE_REF)
+    orf = oracle.render(buf, frame, w, h, sky=sky, mode=0, nthreads=16)
+    assert _same(gr["ids"], orf["ids"]) and _same(gr["t"], orf["t"]) and _same(gr["rgba"], orf["rgba"])
 
 
 def test_both_path_tracing_kernels_give_the_same_image(gpu_pass, oracle, monkeypatch):
