@@ -23,6 +23,10 @@ struct alignas(32) FShade { float4 r0, r1, r2; float4 albedo, specular, emission
 // child / stack words: >= 0 node index; < 0: ~payload, payload bit 30 set = instance rank,
 // clear = (first triangle << 2 | count-1).  kEmptyChild never reaches the stack.
 constexpr int32_t kEmptyChild = (int32_t)0x80000001;
+// Inside a kernel a node word >= 0 with this bit set names a slot of the workgroup's LDS copy of the hot nodes
+// instead of an index into the node array: the child words of the copied nodes are rewritten that way when the copy
+// is made, so that a node step tells where its node lives from the word itself (node indices stay below 2^29).
+constexpr int32_t kHotNodeBit = 1 << 29;
 constexpr uint32_t kInstanceBit = 0x40000000u;
 // FInst::object bit: the instance's mesh is one on which the distance culling of the production kernels was seen
 // to come close to its slack (see RT_GUARD_FACTOR): every ray that enters the instance is handed to the

@@ -542,6 +542,28 @@ __device__ __forceinline__ V3 rowsDir(float4 r0, float4 r1, float4 r2, V3 v) {
               (r2.x * v.x + r2.y * v.y) + r2.z * v.z);
 }
 
+// The word a kernel walks for node `n` of the node array: its slot in the LDS copy when the workgroup holds it
+// (the copy is [0, hotTlas) of the array followed by [blasBase, blasBase + hotBlas)), the index itself otherwise;
+// leaf words (negative) pass through.
+__device__ __forceinline__ int32_t hotWord(int32_t n, int hotTlas, int blasBase, int hotBlas) {
+    if ((uint32_t)n < (uint32_t)hotTlas) return n | kHotNodeBit;
+    if ((uint32_t)(n - blasBase) < (uint32_t)hotBlas) return (hotTlas + (n - blasBase)) | kHotNodeBit;
+    return n;
+}
+// Copy the hot nodes into LDS (seven 16-byte pieces per node), the child words rewritten with hotWord.
+__device__ __forceinline__ void copyHotNodes(float4* ldsNodes, const FastScene& sc, int hotTlas, int hotBlas, int tid) {
+    for (int i = tid; i < (hotTlas + hotBlas) * 8; i += kBlockThreads) {
+        const int n = i >> 3, c = i & 7;
+        const int g = n < hotTlas ? n : sc.blasBase + (n - hotTlas);
+        if (c < 6) ldsNodes[n * kHotStride + c] = reinterpret_cast<const float4*>(sc.nodes + g)[c];
+        else if (c == 6) {
+            const int4 ch = sc.nodes[g].child;
+            ldsNodes[n * kHotStride + 6] = make_float4(__int_as_float(hotWord(ch.x, hotTlas, sc.blasBase, hotBlas)), __int_as_float(hotWord(ch.y, hotTlas, sc.blasBase, hotBlas)),
+                                                       __int_as_float(hotWord(ch.z, hotTlas, sc.blasBase, hotBlas)), __int_as_float(hotWord(ch.w, hotTlas, sc.blasBase, hotBlas)));
+        }
+    }
+}
+
 // The four-box slab test (.compute:233-263), two children per packed instruction.  The
 // products and differences are the same binary32 operations as the scalar form.
 __device__ __forceinline__ void slabPair(f2 lx, f2 hx, f2 ly, f2 hy, f2 lz, f2 hz, f2 ox, f2 oy, f2 oz, f2 ix, f2 iy,
@@ -694,12 +716,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(rtamd_frame
     // gather the vector cache serves one lane per cycle.  The nodes every ray passes through — the
     // TLAS and the first levels of the BLAS trees — are therefore read from an LDS copy.
     const int hotTlas = sc.hotTlas, hotBlas = sc.hotBlas;
-    for (int i = tid; i < (hotTlas + hotBlas) * 8; i += kBlockThreads) {
-        const int n = i >> 3, c = i & 7;
-        const int g = n < hotTlas ? n : sc.blasBase + (n - hotTlas);
-        if (c < 7) ldsNodes[n * kHotStride + c] = reinterpret_cast<const float4*>(sc.nodes + g)[c];
-    }
+    copyHotNodes(ldsNodes, sc, hotTlas, hotBlas, tid);
     __syncthreads();
+    const int32_t rootWord = hotWord(sc.tlasRoot, hotTlas, sc.blasBase, hotBlas);
 
     // pixel state
     bool pixelActive = false, noMoreWork = false;
@@ -858,7 +877,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(rtamd_frame
                 world = next; cur = next;
                 best.t = RT_INF; best.inst = -1; best.tri = -1;
                 secondT = RT_INF; bestNear = 0.0f;
-                node = sc.tlasRoot; sp = 0; instSp = kNoInstance; curInst = -1; spilled = 0;
+                node = rootWord; sp = 0; instSp = kNoInstance; curInst = -1; spilled = 0;
                 trav = true;
                 pixRays++;
                 // (coherent rays -- REF mode, the primary-id pass -- meet exact zeros as a matter of course: the centre

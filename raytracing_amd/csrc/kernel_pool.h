@@ -173,12 +173,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(rtamd_frame
 #define RT_BELOW(m_) ((int)__builtin_amdgcn_mbcnt_hi((uint32_t)((m_) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(m_), 0u)))
 
     const int hotTlas = b.hotTlas, hotBlas = b.hotBlas;
-    for (int i = tid; i < (hotTlas + hotBlas) * 8; i += kBlockThreads) {
-        const int n = i >> 3, c = i & 7;
-        const int g = n < hotTlas ? n : sc.blasBase + (n - hotTlas);
-        if (c < 7) ldsNodes[n * kHotStride + c] = reinterpret_cast<const float4*>(sc.nodes + g)[c];
-    }
+    copyHotNodes(ldsNodes, sc, hotTlas, hotBlas, tid);
     __syncthreads();
+    const int32_t rootWord = hotWord(sc.tlasRoot, hotTlas, sc.blasBase, hotBlas);
 
     // the same in every lane of the wave
     int rayHead = 0, rayTail = 0, hitHead = 0, hitTail = 0, endHead = 0, endTail = 0;
@@ -438,7 +435,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(rtamd_frame
                     cur = world;
                     best.t = RT_INF; best.u = best.v = 0; best.inst = -1; best.tri = -1;
                     secondT = RT_INF; bestNear = 0.0f;
-                    node = sc.tlasRoot; sp = 0; instSp = kNoInstance; curInst = -1; spilled = 0;
+                    node = rootWord; sp = 0; instSp = kNoInstance; curInst = -1; spilled = 0;
                     unsettled = false;
                     trav = true;
                 }
@@ -463,7 +460,7 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(rtamd_frame
                     cur = world;
                     best.t = RT_INF; best.u = best.v = 0; best.inst = -1; best.tri = -1;
                     secondT = RT_INF; bestNear = 0.0f;
-                    node = sc.tlasRoot; sp = 0; instSp = kNoInstance; curInst = -1; spilled = 0;
+                    node = rootWord; sp = 0; instSp = kNoInstance; curInst = -1; spilled = 0;
                     unsettled = false;
                     trav = true;
                 }
@@ -675,9 +672,11 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         // measured optima of the three benchmark scenes: shading is cheap here (full waves), so
         // lanes are refilled earlier than in kFast; small scenes (same criterion as kFast's) walk on with few lanes
         const bool allHot = fs.nBlasNodes + (size_t)fs.nTlasNodes <= (size_t)kPoolHotNodes;
-        if (cfg.refillBelow == 0) cfg.refillBelow = allHot ? 40 : 44;
+        // (re-swept on the round's final kernels, tools/sweep_thresholds.sh: every node in LDS 12 / 36; nodes beyond LDS
+        // but few enough for L2, the small-scene variant, 28 / 48; the large-scene variant 24 / 44)
+        if (cfg.refillBelow == 0) cfg.refillBelow = allHot ? 36 : (big ? 44 : 48);
         if (cfg.nodeMin == 0) {
-            cfg.nodeMin = allHot ? 12 : 24;
+            cfg.nodeMin = allHot ? 12 : (big ? 24 : 28);
             // a frame of one or two samples per pixel is over before the waves fall out of step: there the shorter
             // chain of steps counts for more than full node steps (1M-triangle scene, 1 spp: 2.47 -> 2.34 ms)
             const unsigned long long paths = (unsigned long long)fs.hSuper.size() * 1024ull * (unsigned long long)a.spp;
