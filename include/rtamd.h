@@ -91,7 +91,13 @@ enum {
     RTAMD_FLAG_OUTPUT_SUM      = 1 << 3, /* PT: write the un-normalised sample sum (for cross-GPU sample sharding) */
     RTAMD_FLAG_COUNTERS        = 1 << 4, /* also fill the work counters (forces REFERENCE_ORDER so the counts are the reference's) */
     RTAMD_FLAG_SHARD_SAMPLES   = 1 << 5, /* PT on a context over several GPUs: split the samples, not the tiles, over the GPUs */
-    RTAMD_FLAG_DIELECTRICS     = 1 << 6  /* PT: objects whose specular[3] is RTAMD_MATERIAL_DIELECTRIC transmit light (see below) */
+    RTAMD_FLAG_DIELECTRICS     = 1 << 6, /* PT: objects whose specular[3] is RTAMD_MATERIAL_DIELECTRIC transmit light (see below) */
+    RTAMD_FLAG_DEBUG_CHECKS    = 1 << 7  /* diagnostic: run the bounds-checked variant of the production kernel (one path per lane): every node,
+                                            instance, triangle and stack index is checked against the scene's sizes before it is
+                                            followed; a violation ends that pixel and the call returns RTAMD_ERR_BAD_INDEX.  Same image on an
+                                            intact scene, at about the speed of RTAMD_PIPELINE=persistent.  Not together with DIELECTRICS,
+                                            REFERENCE_ORDER, COUNTERS or rtamd_render_begin (RTAMD_ERR_INVALID_ARG).  No counterpart in the
+                                            reference, whose shader trusts its buffers. */
 };
 
 /* Dielectric extension (no counterpart in the reference: RayTraceMaterial.cs:12-17 has no

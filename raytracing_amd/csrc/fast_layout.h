@@ -51,6 +51,7 @@ struct FastScene {
     const float* planes;
     const int32_t* planeRange;
     int32_t planeTlas;
+    int32_t nNodes, nInst, nTriRecords, nTriangles;      // entries in use of nodes / inst (and shade) / tris / nrms (and triOrig): what the bounds-checked kernel variant compares with
     int32_t* stackSpill;         // overflow of the LDS traversal stacks: [spillMax][threads of the grid]
     int32_t spillMax;            // overflow entries per lane (0: none, a deeper stack hands its pixel over at once)
 };

@@ -76,6 +76,7 @@ struct FastSceneHost {
     DBuf<int32_t> stackSpill;
     DBuf<unsigned long long> stats;
     std::vector<int32_t> blasRoot;     // wide-node index of each BLAS root
+    int32_t nTriRecords = 0, nTriangles = 0;   // entries of tris / of nrms and triOrig in use (the bounds-checked kernel variant compares with them)
     // node array: [0, tlasReserve) the TLAS of the last upload (breadth first), then every BLAS node,
     // the top levels of all BLAS trees first (breadth first, round robin over the trees)
     std::vector<WNode> hNodes;
@@ -370,6 +371,7 @@ struct FastSceneHost {
         if ((e = guardBlas.ensure((size_t)nBlas)) != hipSuccess || (e = blasDemoted.ensure((size_t)nBlas)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(guardBlas.p, 0, (size_t)nBlas * sizeof(int32_t), stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(blasDemoted.p, 0, (size_t)nBlas * sizeof(int32_t), stream)) != hipSuccess) return e;
+        nTriRecords = (int32_t)ft.size(); nTriangles = (int32_t)fn.size();
         if ((e = tris.put(ft, stream)) != hipSuccess) return e;
         if ((e = nrms.put(fn, stream)) != hipSuccess) return e;
         if ((e = triOrig.put(orig, stream)) != hipSuccess) return e;
@@ -695,7 +697,9 @@ __device__ __forceinline__ Surf resolveHit(const FastScene& sc, const Ray& world
 // executed it and with how many active lanes (written to `stats`, 16 counters).
 // DIEL = true (PT mode with RTAMD_FLAG_DIELECTRICS): glass objects refract; a path inside glass tests
 // triangles from both sides.
-template <int MODE, bool STATS, bool DIEL = false>
+// CHECKED = true (RTAMD_FLAG_DEBUG_CHECKS): the diagnostic variant compares every node, instance, triangle and stack
+// index with the scene's sizes before following it; an index outside ends the pixel and sets bit 8 of the error flag.
+template <int MODE, bool STATS, bool DIEL = false, bool CHECKED = false>
 __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(rtamd_frame_cbuffer camera /* first: see cameraArg */, FastScene sc, Sky sky, RenderArgs a, int refillBelow, int nodeMin, int leafGroupMin,
                                                        int stackLimit, unsigned long long* stats) {
     unsigned long long st_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -774,6 +778,10 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(rtamd_frame
             // another triangle was hit before the winner's own boxes are entered: the reference's answer
             // depends on its visiting order
             if (pathActive && best.t < RT_INF && secondT < bestNear) RT_REDO();
+            if (CHECKED && pathActive && best.t < RT_INF && !((uint32_t)best.inst < (uint32_t)sc.nInst && (uint32_t)(best.tri & ~kBackFaceBit) < (uint32_t)sc.nTriangles)) {
+                atomicOr(a.errorFlag, 8);
+                pixelActive = false; pathActive = false; pixRays = 0;
+            }
             if (pathActive) {
                 // the segment just traversed
                 if (best.t < RT_INF) {
@@ -893,7 +901,9 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(rtamd_frame
 #define RT_TWO_SIDED (DIEL && insideGlass)
 #define RT_KEEP_HIT(t_, u_, v_, tri_) do { best.u = (u_); best.v = (v_); } while (0)
 #define RT_LOCAL_RAY_UNSETTLED(rank_) (rayDegenerate(cur) && (MODE == kModePt || !planesClear(sc, __float_as_int(sc.inst[rank_].pad.x), cur)))
+#define RT_BAD_INDEX() do { atomicOr(a.errorFlag, 8); pixelActive = false; pathActive = false; trav = false; pixRays = 0; } while (0)
 #include "traverse_body.inc"
+#undef RT_BAD_INDEX
 #undef RT_LOCAL_RAY_UNSETTLED
 #undef RT_KEEP_HIT
 #undef RT_TWO_SIDED
@@ -1008,6 +1018,7 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
     sc.tris = fs.tris.p; sc.nrms = fs.nrms.p; sc.triOrig = fs.triOrig.p; sc.nSuperTiles = (int)fs.hSuper.size();
     sc.tlasRoot = fs.tlasRoot;
     sc.planes = fs.planes.p; sc.planeRange = fs.planeRange.p; sc.planeTlas = fs.nBlasOfScene;
+    sc.nNodes = (int32_t)fs.hNodes.size(); sc.nInst = fs.nInst; sc.nTriRecords = fs.nTriRecords; sc.nTriangles = fs.nTriangles;
     if (lent) {
         sc.superTiles = lent->superTiles;
         // (the kernel indexes the area by gridDim.x: whole chunks per lane of the grid actually launched)
@@ -1054,6 +1065,37 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
             if (h[2 * i]) fprintf(stderr, "[rtamd stats] %-22s executions %12llu  mean active lanes %6.2f\n", names[i], h[2 * i], (double)h[2 * i + 1] / (double)h[2 * i]);
         fprintf(stderr, "[rtamd stats] deepest traversal stack %llu of %d entries\n", h[15], kLdsStack);
         return hipSuccess;
+    }
+    if (a.flags & RTAMD_FLAG_DEBUG_CHECKS) {
+        // the bounds-checked diagnostic variant (glass objects are not part of it: RTAMD_FLAG_DIELECTRICS is refused with it)
+        // Test hook RTAMD_TEST_DAMAGE = node | inst | tri: for this launch only (the word is put back in stream order
+        // behind the kernel) one child word of the scene's tree names a node, an instance or a triangle range that
+        // does not exist.  Only here, where every index is compared before it is followed.
+        int32_t* damaged = nullptr;
+        int32_t saved = 0;
+        if (const char* what = getenv("RTAMD_TEST_DAMAGE")) {
+            int32_t word = 0;
+            if (!strcmp(what, "node") && !fs.blasRoot.empty() && fs.blasRoot[0] >= 0) { damaged = &fs.nodes.p[fs.blasRoot[0]].child.x; word = 0x0FFFFFFF; }
+            else if (!strcmp(what, "tri") && !fs.blasRoot.empty() && fs.blasRoot[0] >= 0) { damaged = &fs.nodes.p[fs.blasRoot[0]].child.x; word = ~(int32_t)((0x00FFFFFFu << 2) | 1u); }
+            else if (!strcmp(what, "inst")) { damaged = &fs.nodes.p[sc.tlasRoot].child.x; word = ~(int32_t)(0x00FFFFFFu | kInstanceBit); }
+            if (damaged) {
+                hipError_t e = hipMemcpy(&saved, damaged, sizeof saved, hipMemcpyDeviceToHost);
+                if (e == hipSuccess) e = hipMemcpyAsync(damaged, &word, sizeof word, hipMemcpyHostToDevice, stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                if (e != hipSuccess) return e;
+            }
+        }
+        if (a.mode == RTAMD_MODE_PT)
+            hipLaunchKernelGGL((kFast<kModePt, false, false, true>), dim3(grid), dim3(kBlockThreads), 0, stream, a.cb, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
+        else
+            hipLaunchKernelGGL((kFast<kModeRef, false, false, true>), dim3(grid), dim3(kBlockThreads), 0, stream, a.cb, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);
+        hipError_t le = hipGetLastError();
+        if (damaged) {
+            hipError_t e = hipStreamSynchronize(stream);
+            if (e == hipSuccess) e = hipMemcpy(damaged, &saved, sizeof saved, hipMemcpyHostToDevice);
+            if (le == hipSuccess) le = e;
+        }
+        return le;
     }
     if (a.mode == RTAMD_MODE_PT && (a.flags & RTAMD_FLAG_DIELECTRICS))
         hipLaunchKernelGGL((kFast<kModePt, false, true>), dim3(grid), dim3(kBlockThreads), 0, stream, a.cb, sc, sky, a, cfg.refillBelow, cfg.nodeMin, cfg.leafGroupMin, cfg.stackLimit, (unsigned long long*)nullptr);

@@ -478,7 +478,10 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kPool(rtamd_frame
         // the closest hit's t, u, v, triangle go straight to the slot's LDS entry (two registers less to carry)
 #define RT_KEEP_HIT(t_, u_, v_, tri_) do { ldsHit[wave][slot] = make_float4((t_), (u_), (v_), __int_as_float(tri_)); } while (0)
 #define RT_LOCAL_RAY_UNSETTLED(rank_) rayDegenerate(cur)
+#define RT_BAD_INDEX() do { } while (0)
+        constexpr bool CHECKED = false;      // (the bounds-checked diagnostic variant is kFast's)
 #include "traverse_body.inc"
+#undef RT_BAD_INDEX
 #undef RT_LOCAL_RAY_UNSETTLED
 #undef RT_KEEP_HIT
 #undef RT_TWO_SIDED
@@ -689,6 +692,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     sc.tris = fs.tris.p; sc.nrms = fs.nrms.p; sc.triOrig = fs.triOrig.p; sc.superTiles = fs.superTiles.p; sc.nSuperTiles = (int)fs.hSuper.size();
     sc.tlasRoot = fs.tlasRoot;
     sc.planes = fs.planes.p; sc.planeRange = fs.planeRange.p; sc.planeTlas = fs.nBlasOfScene;
+    sc.nNodes = (int32_t)fs.hNodes.size(); sc.nInst = fs.nInst; sc.nTriRecords = fs.nTriRecords; sc.nTriangles = fs.nTriangles;
     if ((e = fs.stackSpill.ensure((size_t)kSpillMax * (size_t)(numCU * cfg.blocksPerCU) * kBlockThreads)) != hipSuccess) return e;
     sc.stackSpill = fs.stackSpill.p;
     sc.spillMax = kSpillMax;

@@ -579,6 +579,8 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
     a.shardRank = e.shard_rank; a.shardCount = e.shard_count;
     a.flags = e.flags;
     if ((e.flags & RTAMD_FLAG_COUNTERS) && !e.out_counters) return fail(c, RTAMD_ERR_INVALID_ARG, "RTAMD_FLAG_COUNTERS needs ext.out_counters");
+    if ((e.flags & RTAMD_FLAG_DEBUG_CHECKS) && (e.flags & (RTAMD_FLAG_DIELECTRICS | RTAMD_FLAG_REFERENCE_ORDER | RTAMD_FLAG_COUNTERS)))
+        return fail(c, RTAMD_ERR_INVALID_ARG, "RTAMD_FLAG_DEBUG_CHECKS is a variant of the production kernel without glass: not together with DIELECTRICS, REFERENCE_ORDER or COUNTERS");
     bool wantCounters = (e.flags & RTAMD_FLAG_COUNTERS) != 0;
     bool faithful = (e.flags & RTAMD_FLAG_REFERENCE_ORDER) || wantCounters;
 
@@ -647,7 +649,7 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
         } else {
             // (the path pool needs record and sample buffers sized to the frame: without allocations PT mode
             // runs one path per lane, which gives the same image bit for bit)
-            usedPool = a.mode == RTAMD_MODE_PT && rt::fastLaunchConfig().pool && !noAlloc;
+            usedPool = a.mode == RTAMD_MODE_PT && rt::fastLaunchConfig().pool && !noAlloc && !(a.flags & RTAMD_FLAG_DEBUG_CHECKS);
             hipError_t le = usedPool ? rt::launchPool(c->fast, c->pool, sky, a, c->stream, rsc, (int32_t*)(ctrl + kNaOffPathCount), (int32_t*)(ctrl + kNaOffPathCount + 8), (int32_t*)(ctrl + kNaOffPathCount + 4))
                                      : rt::launchFast(c->fast, sky, a, c->stream, noAlloc ? &lent : nullptr);
             if (le != hipSuccess) return failHip(c, le, "production kernel launch");
@@ -772,6 +774,7 @@ static int renderCore(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rtam
         oc->rays = hc.rays; oc->nodes = hc.nodes; oc->tris = hc.tris; oc->instances = hc.instances; oc->hits = hc.hits;
         oc->max_blas_stack = hc.maxBlasStack; oc->max_tlas_stack = hc.maxTlasStack; oc->reserved = hc.overflow;
     }
+    if (herr & 8) return fail(c, RTAMD_ERR_BAD_INDEX, "bounds-checked kernel: an index outside the scene's arrays was about to be followed (device memory of the scene damaged, or a fault of the library)");
     if (herr & 1) return fail(c, RTAMD_ERR_STACK_OVERFLOW, "traversal stack overflow (scene deeper than the shader's stacks allow)");
     if (herr & 4) return fail(c, RTAMD_ERR_OUT_OF_MEMORY, noAlloc ? "rtamd_render_noalloc: more than 65536 pixels needed the reference-order kernel; render this frame with rtamd_render"
                                                                     : "hand-over list overflow");
@@ -1162,7 +1165,7 @@ int rtamd_render_begin(rtamd_ctx* c, const rtamd_frame_cbuffer* frame, const rta
     if (e.mode == RTAMD_MODE_PT && (e.spp < 1 || e.max_bounces < 0 || e.sample_offset < 0))
         return fail(c, RTAMD_ERR_INVALID_ARG, "PT mode needs spp >= 1, max_bounces >= 0, sample_offset >= 0");
     if (e.shard_count > 1 && (e.shard_rank < 0 || e.shard_rank >= e.shard_count)) return fail(c, RTAMD_ERR_INVALID_ARG, "shard_rank out of range");
-    if (e.flags & (RTAMD_FLAG_COUNTERS | RTAMD_FLAG_REFERENCE_ORDER)) return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_begin: counters and reference order are for rtamd_render");
+    if (e.flags & (RTAMD_FLAG_COUNTERS | RTAMD_FLAG_REFERENCE_ORDER | RTAMD_FLAG_DEBUG_CHECKS)) return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_begin: counters, reference order and the bounds-checked variant are for rtamd_render");
     if ((out_rgba_device && !isDevicePointer(out_rgba_device)) || (out_prim_id_device && !isDevicePointer(out_prim_id_device)) || (e.out_t && !isDevicePointer(e.out_t)))
         return fail(c, RTAMD_ERR_INVALID_ARG, "rtamd_render_begin: outputs must be device memory");
     HIP_TRY(c, hipSetDevice(c->device));

@@ -23,8 +23,10 @@ assert OBJECT.itemsize == 180 and FRAME.itemsize == 144
 
 MODE_REF, MODE_PT = 0, 1
 FLAG_ACCUMULATE, FLAG_NO_JITTER, FLAG_REFERENCE_ORDER, FLAG_OUTPUT_SUM, FLAG_COUNTERS, FLAG_SHARD_SAMPLES, FLAG_DIELECTRICS = 1, 2, 4, 8, 16, 32, 64
+FLAG_DEBUG_CHECKS = 128
 MATERIAL_DIELECTRIC = 2.0
 
+ERR_INVALID_ARG, ERR_BAD_INDEX, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_STACK_OVERFLOW, ERR_NO_SCENE, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
 ERRORS = {0: "OK", -1: "INVALID_ARG", -2: "BAD_INDEX", -3: "OUT_OF_MEMORY", -4: "HIP", -5: "STACK_OVERFLOW",
           -6: "NO_SCENE", -7: "NO_DEVICE"}
 
