@@ -224,6 +224,23 @@ int rtamd_scene_refresh_objects(rtamd_ctx* ctx,
 #define RTAMD_TLAS_BUILD_DEVICE 2
 int rtamd_set_tlas_build(rtamd_ctx* ctx, int32_t mode);
 
+/* Who builds the library's own trees over the meshes at rtamd_scene_upload.  The reference bakes its
+ * bottom-level trees at edit time (Assets/Editor/RayTracing/Authoring/RayTraceableBaker.cs:75-149) and the caller
+ * still passes those: they give every triangle its leaf-slot box and its place in the visiting order, which decide
+ * hits and ties.  The hierarchy the production kernels walk is rebuilt: on the host (binned SAH on up to 8 threads,
+ * the tree that traces fastest; AUTO and HOST) or on the GPU (Morton order, neighbours paired into leaves, binary
+ * radix tree collapsed to 4-wide nodes: milliseconds per million triangles, for meshes that change between frames;
+ * meshes below 256 triangles stay with the host builder).  Which triangle a ray hits does not depend on the choice.
+ * Takes effect at the next rtamd_scene_upload. */
+#define RTAMD_BLAS_BUILD_AUTO 0
+#define RTAMD_BLAS_BUILD_HOST 1
+#define RTAMD_BLAS_BUILD_DEVICE 2
+int rtamd_set_blas_build(rtamd_ctx* ctx, int32_t mode);
+
+/* The last rtamd_scene_upload: wall-clock time of the whole call, the part of it spent building the meshes'
+ * trees, and how many meshes' trees the GPU built.  Any pointer may be NULL.  (No counterpart in the reference.) */
+int rtamd_last_upload_stats(const rtamd_ctx* ctx, float* upload_ms, float* tree_build_ms, int32_t* meshes_built_on_device);
+
 /* Shape of that private tree after the last upload / refresh: number of 4-wide nodes,
  * number of levels, and whether it was built on the GPU (1) or the host (0).  Any
  * pointer may be NULL. */

@@ -16,7 +16,7 @@ _lib = None
 
 EXPORTS = ["rtamd_ctx_create", "rtamd_ctx_create_multi", "rtamd_multi_info", "rtamd_multi_exchange_note", "rtamd_ctx_destroy", "rtamd_last_error_string", "rtamd_scene_upload",
            "rtamd_scene_refresh_objects", "rtamd_sky_upload", "rtamd_render", "rtamd_render_noalloc", "rtamd_render_begin", "rtamd_render_wait", "rtamd_accum_download", "rtamd_accum_upload", "rtamd_accum_reset",
-           "rtamd_set_stream", "rtamd_set_tlas_build", "rtamd_tlas_info", "rtamd_last_render_stats", "rtamd_last_trace_kernel_ms", "rtamd_last_handover_stats", "rtamd_last_guard_stats", "rtamd_composite_add", "rtamd_present", "rtamd_version"]
+           "rtamd_set_stream", "rtamd_set_tlas_build", "rtamd_set_blas_build", "rtamd_last_upload_stats", "rtamd_tlas_info", "rtamd_last_render_stats", "rtamd_last_trace_kernel_ms", "rtamd_last_handover_stats", "rtamd_last_guard_stats", "rtamd_composite_add", "rtamd_present", "rtamd_version"]
 
 
 class BackendError(RuntimeError):
@@ -56,6 +56,8 @@ def lib():
         L.rtamd_accum_reset.argtypes = [C.c_void_p]
         L.rtamd_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.rtamd_set_tlas_build.argtypes = [C.c_void_p, C.c_int32]
+        L.rtamd_set_blas_build.argtypes = [C.c_void_p, C.c_int32]
+        L.rtamd_last_upload_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.rtamd_tlas_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.rtamd_last_render_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
         L.rtamd_last_handover_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
@@ -164,6 +166,16 @@ class RayTracingPass:
         """'auto' | 'host' | 'device': who rebuilds the library's private tree over the instances
         (the reference's per-frame TLAS build, BuildAccelerateStructureSystem.cs:56-66)."""
         self._check(lib().rtamd_set_tlas_build(self._ctx, {"auto": 0, "host": 1, "device": 2}[mode]))
+
+    def SetBlasBuild(self, mode):
+        """'auto' | 'host' | 'device': who builds the library's private trees over the meshes at the next SetScene
+        (the reference bakes its own at edit time, RayTraceableBaker.cs:75-149)."""
+        self._check(lib().rtamd_set_blas_build(self._ctx, {"auto": 0, "host": 1, "device": 2}[mode]))
+
+    def UploadStats(self):
+        ms, tree, dev = C.c_float(0), C.c_float(0), C.c_int32(0)
+        self._check(lib().rtamd_last_upload_stats(self._ctx, C.byref(ms), C.byref(tree), C.byref(dev)))
+        return {"upload_ms": ms.value, "tree_build_ms": tree.value, "meshes_built_on_device": dev.value}
 
     def TlasInfo(self):
         n, lv, dev = C.c_int32(0), C.c_int32(0), C.c_int32(0)

@@ -34,7 +34,7 @@
 //                 the TLAS in front (breadth first, one slot per object reserved), then the BLAS nodes level by level
 //   FTri    64 B  per triangle: leaf-slot box lo.xyz, hi.xyz, v0, e1, e2, rank (= position in the reference's visiting
 //                 order); stored in leaf order of the new tree, two records to a 128-byte line, the pair interleaved
-//                 component by component (interleaveLeaf)
+//                 component by component (kGatherLeafRecords, tlas_build.hip)
 //   FNrm    48 B  n0,n1,n2, indexed by rank                  — read once per closest hit
 //   FInst   96 B  three rows of WorldToLocal, the instance's TLAS slot box, BLAS root, original object index
 //   FShade  96 B  three rows of LocalToWorld, albedo, specular, emission
@@ -42,6 +42,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -123,6 +124,10 @@ struct FastSceneHost {
     // who builds the tree over the instances: 0 = by instance count, 1 = host (binned SAH), 2 = device (Morton order)
     int tlasBuildMode = 0;
     bool tlasBuiltOnDevice = false;
+    // who builds the trees of the meshes at upload: 0 / 1 = host (binned SAH), 2 = device (Morton order); what the last upload did
+    int blasBuildMode = 0;
+    int blasBuiltOnDevice = 0;
+    float blasBuildMs = 0.f;
     TlasDeviceBuilder* tlasBuilder = nullptr;
 
     void release() {
@@ -174,33 +179,34 @@ struct FastSceneHost {
         levelStart.push_back((int32_t)order.size());
     }
 
-    // A two-triangle leaf is one 128-byte line holding the two records component by component — 16 pairs
-    // (triangle 0, triangle 1): lo.xyz, hi.xyz, v0.xyz, e1.xyz, e2.xyz, rank — so that the kernel tests both
-    // slot boxes and both triangles with two-wide instructions.  `pair` points at the two records as gathered.
-    static void interleaveLeaf(FTri* pair) {
-        static const int kComponent[16] = {0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 6};
-        float in[2][16], out[32];
-        std::memcpy(in, pair, sizeof(in));
-        for (int j = 0; j < 16; j++) { out[2 * j] = in[0][kComponent[j]]; out[2 * j + 1] = in[1][kComponent[j]]; }
-        std::memcpy(pair, out, sizeof(out));
-    }
-
-    // sort every set and drop repeated values (NaN bounds cannot equal a ray's origin and are dropped too)
-    static void sortPlaneSets(std::vector<std::vector<float>>& sets) {
-        auto one = [](std::vector<float>& v) {
-            v.erase(std::remove_if(v.begin(), v.end(), [](float x) { return x != x; }), v.end());
-            std::sort(v.begin(), v.end());
-            v.erase(std::unique(v.begin(), v.end()), v.end());
+    // sort every set and drop repeated values (NaN bounds cannot equal a ray's origin and are dropped too).  On up to
+    // 6 host threads, one set each; with a device builder the sets of 65 536 values and more are sorted by the GPU's
+    // radix sort in between (a mesh of a million triangles has three sets of 2-3 million bounds).
+    static hipError_t sortPlaneSets(std::vector<std::vector<float>>& sets, TlasDeviceBuilder* dev = nullptr, hipStream_t stream = nullptr) {
+        constexpr size_t kDeviceFrom = (size_t)1 << 16;
+        auto onThreads = [&sets](void (*one)(std::vector<float>&, bool), bool flag) {
+            const size_t nThreads = sets.size() < 6 ? sets.size() : 6;
+            std::vector<std::thread> th;
+            std::atomic<size_t> next{0};
+            auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < sets.size();) one(sets[k], flag); };
+            try {
+                for (size_t t = 1; t < nThreads; t++) th.emplace_back(work);
+            } catch (...) { }      // (fewer threads: the caller's thread does the rest)
+            work();
+            for (auto& t : th) t.join();
         };
-        const size_t nThreads = sets.size() < 6 ? sets.size() : 6;
-        std::vector<std::thread> th;
-        std::atomic<size_t> next{0};
-        auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < sets.size();) one(sets[k]); };
-        try {
-            for (size_t t = 1; t < nThreads; t++) th.emplace_back(work);
-        } catch (...) { }      // (fewer threads: the caller's thread does the rest)
-        work();
-        for (auto& t : th) t.join();
+        onThreads([](std::vector<float>& v, bool haveDevice) {
+            v.erase(std::remove_if(v.begin(), v.end(), [](float x) { return x != x; }), v.end());
+            if (!haveDevice || v.size() < kDeviceFrom) std::sort(v.begin(), v.end());
+        }, dev != nullptr);
+        if (dev)
+            for (std::vector<float>& v : sets)
+                if (v.size() >= kDeviceFrom) {
+                    const hipError_t e = sortFloatsOnDevice(dev, v.data(), v.size(), stream);
+                    if (e != hipSuccess) return e;
+                }
+        onThreads([](std::vector<float>& v, bool) { v.erase(std::unique(v.begin(), v.end()), v.end()); }, false);
+        return hipSuccess;
     }
 
     // Re-build every BLAS.  Inputs were validated by the caller (indices in range, every
@@ -211,50 +217,113 @@ struct FastSceneHost {
                            const int32_t* vtxOffsets, const rtamd_vertex* verts, const int32_t* triOffsets,
                            const rtamd_int3* tris_, const int32_t* triCount, int nBlas, int tlasReserve_,
                            hipStream_t stream, std::string& err) {
-        (void)triCount; (void)nodeCount;
         tlasReserve = tlasReserve_ < 1 ? 1 : tlasReserve_;
         hNodes.clear();
         std::vector<WideTree> trees((size_t)nBlas);
         std::vector<uint32_t> triBases((size_t)nBlas);
-        std::vector<FTri> ft;          // in leaf order of the new trees
-        std::vector<FNrm> fn;          // by global rank
-        std::vector<int32_t> orig;     // by global rank: the caller's triangle index
         blasRoot.assign(nBlas, 0);
         maxDepth = 0;
+        blasBuiltOnDevice = 0;
+        blasBuildMs = 0.f;
         std::vector<std::vector<float>> planeSets((size_t)nBlas * 3);
-        for (int b = 0; b < nBlas; b++) {
-            const rtamd_node* nodes_ = blas + blasOffsets[b];
-            const rtamd_int3* tri = tris_ + triOffsets[b];
-            const rtamd_vertex* vtx = verts + vtxOffsets[b];
-            const size_t rankBase = fn.size();
-            std::vector<BuildBox> boxes;
-            std::vector<FTri> ranked;
+        // (RTAMD_VERBOSE: where the time of an upload goes)
+        float phaseMs[6] = {0, 0, 0, 0, 0, 0};
+        auto clockNow = [] { return std::chrono::steady_clock::now(); };
+        auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+        auto tPhase = clockNow();
+        // Pass 1, one thread: the visiting order.  Per mesh the leaf slots that hold a triangle, in the order the
+        // reference reaches them (node << 2 | slot), and the nodes visited with the number of used slots before each
+        // (where the node's box bounds go in the tables of bounds).
+        struct Walk {
+            std::vector<uint32_t> slots;
+            std::vector<int32_t> visited;
+            std::vector<uint32_t> usedBefore;
+            size_t rankBase = 0, usedSlots = 0;
+        };
+        std::vector<Walk> walks((size_t)nBlas);
+        size_t nRanked = 0;
+        {
             std::vector<int32_t> st;
-            st.push_back(1);
-            while (!st.empty()) {
-                int ni = st.back();
-                st.pop_back();
-                const rtamd_node& n = nodes_[ni];
-                for (int i = 0; i < 4; i++)
-                    if (n.Flags == 0 ? n.Data[i] != 0 : n.Data[i] != -1) {
-                        planeSets[(size_t)b * 3 + 0].push_back(n.Lx[i]); planeSets[(size_t)b * 3 + 0].push_back(n.Hx[i]);
-                        planeSets[(size_t)b * 3 + 1].push_back(n.Ly[i]); planeSets[(size_t)b * 3 + 1].push_back(n.Hy[i]);
-                        planeSets[(size_t)b * 3 + 2].push_back(n.Lz[i]); planeSets[(size_t)b * 3 + 2].push_back(n.Hz[i]);
+            for (int b = 0; b < nBlas; b++) {
+                if (nodeCount[b] >= (1 << 29)) { err = "too many nodes in one BLAS"; return hipSuccess; }
+                const rtamd_node* nodes_ = blas + blasOffsets[b];
+                Walk& wk = walks[(size_t)b];
+                wk.rankBase = nRanked;
+                wk.slots.reserve((size_t)triCount[b]);
+                wk.visited.reserve((size_t)nodeCount[b]);
+                wk.usedBefore.reserve((size_t)nodeCount[b]);
+                st.clear();
+                st.push_back(1);
+                uint32_t used = 0;
+                while (!st.empty()) {
+                    const int ni = st.back();
+                    st.pop_back();
+                    const rtamd_node& n = nodes_[ni];
+                    wk.visited.push_back(ni);
+                    wk.usedBefore.push_back(used);
+                    if (n.Flags == 0) {
+                        for (int i = 0; i < 4; i++) if (n.Data[i] != 0) { st.push_back(n.Data[i]); used++; }
+                        continue;
                     }
-                if (n.Flags == 0) {
-                    for (int i = 0; i < 4; i++) if (n.Data[i] != 0) st.push_back(n.Data[i]);
-                    continue;
+                    for (int i = 0; i < 4; i++)
+                        if (n.Data[i] != -1) { wk.slots.push_back(((uint32_t)ni << 2) | (uint32_t)i); used++; }
                 }
-                for (int i = 0; i < 4; i++) {
-                    int t = n.Data[i];
-                    if (t == -1) continue;
+                wk.usedSlots = used;
+                nRanked += wk.slots.size();
+                if (nRanked >= (1u << 28)) { err = "too many triangles for the leaf encoding"; return hipSuccess; }
+            }
+        }
+        // Pass 2, on up to 8 threads: the records.  Per triangle (by rank) its leaf-slot box, vertex, edges and rank
+        // (`ranked`), its box for the tree builder, its normals and the caller's index; per used slot its six bounds.
+        std::vector<FTri> ranked(nRanked);     // by global rank
+        std::vector<FNrm> fn(nRanked);         // by global rank
+        std::vector<int32_t> orig(nRanked);    // by global rank: the caller's triangle index
+        std::vector<std::vector<BuildBox>> boxesOf((size_t)nBlas);
+        {
+            struct Chunk { int blas, kind; size_t lo, hi; };
+            std::vector<Chunk> chunks;
+            constexpr size_t kChunk = 8192;
+            for (int b = 0; b < nBlas; b++) {
+                const Walk& wk = walks[(size_t)b];
+                boxesOf[(size_t)b].resize(wk.slots.size());
+                for (int k = 0; k < 3; k++) planeSets[(size_t)b * 3 + k].resize(2 * wk.usedSlots);
+                for (size_t lo = 0; lo < wk.slots.size(); lo += kChunk) chunks.push_back({b, 0, lo, std::min(lo + kChunk, wk.slots.size())});
+                for (size_t lo = 0; lo < wk.visited.size(); lo += kChunk) chunks.push_back({b, 1, lo, std::min(lo + kChunk, wk.visited.size())});
+            }
+            auto fill = [&](const Chunk& c) {
+                const rtamd_node* nodes_ = blas + blasOffsets[c.blas];
+                const Walk& wk = walks[(size_t)c.blas];
+                if (c.kind == 1) {
+                    float* px = planeSets[(size_t)c.blas * 3 + 0].data();
+                    float* py = planeSets[(size_t)c.blas * 3 + 1].data();
+                    float* pz = planeSets[(size_t)c.blas * 3 + 2].data();
+                    for (size_t v = c.lo; v < c.hi; v++) {
+                        const rtamd_node& n = nodes_[wk.visited[v]];
+                        size_t at = 2 * (size_t)wk.usedBefore[v];
+                        for (int i = 0; i < 4; i++)
+                            if (n.Flags == 0 ? n.Data[i] != 0 : n.Data[i] != -1) {
+                                px[at] = n.Lx[i]; px[at + 1] = n.Hx[i];
+                                py[at] = n.Ly[i]; py[at + 1] = n.Hy[i];
+                                pz[at] = n.Lz[i]; pz[at + 1] = n.Hz[i];
+                                at += 2;
+                            }
+                    }
+                    return;
+                }
+                const rtamd_int3* tri = tris_ + triOffsets[c.blas];
+                const rtamd_vertex* vtx = verts + vtxOffsets[c.blas];
+                BuildBox* boxes = boxesOf[(size_t)c.blas].data();
+                for (size_t r = c.lo; r < c.hi; r++) {
+                    const rtamd_node& n = nodes_[wk.slots[r] >> 2];
+                    const int i = (int)(wk.slots[r] & 3u);
+                    const int t = n.Data[i];
                     const float* p0 = vtx[tri[t].x].position;
                     const float* p1 = vtx[tri[t].y].position;
                     const float* p2 = vtx[tri[t].z].position;
                     // e1 = v1 - v0, e2 = v2 - v0: the same binary32 subtractions Trisection does (:201-202)
-                    float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
-                    float e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
-                    int32_t rank = (int32_t)(rankBase + ranked.size());
+                    const float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+                    const float e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+                    const int32_t rank = (int32_t)(wk.rankBase + r);
                     float rk;
                     std::memcpy(&rk, &rank, 4);
                     FTri f;
@@ -262,9 +331,8 @@ struct FastSceneHost {
                     f.b = make_float4(n.Hy[i], n.Hz[i], rk, p0[0]);
                     f.c = make_float4(p0[1], p0[2], e1[0], e1[1]);
                     f.d = make_float4(e1[2], e2[0], e2[1], e2[2]);
-                    ranked.push_back(f);
-                    BuildBox bx = {{n.Lx[i], n.Ly[i], n.Lz[i]}, {n.Hx[i], n.Hy[i], n.Hz[i]}};
-                    boxes.push_back(bx);
+                    ranked[(size_t)rank] = f;
+                    boxes[r] = {{n.Lx[i], n.Ly[i], n.Lz[i]}, {n.Hx[i], n.Hy[i], n.Hz[i]}};
                     const float* n0 = vtx[tri[t].x].normal;
                     const float* n1 = vtx[tri[t].y].normal;
                     const float* n2 = vtx[tri[t].z].normal;
@@ -272,33 +340,61 @@ struct FastSceneHost {
                     g.a = make_float4(n0[0], n0[1], n0[2], n1[0]);
                     g.b = make_float4(n1[1], n1[2], n2[0], n2[1]);
                     g.c = make_float4(n2[2], 0.f, 0.f, 0.f);
-                    fn.push_back(g);
-                    orig.push_back(t);
+                    fn[(size_t)rank] = g;
+                    orig[(size_t)rank] = t;
                 }
-            }
-            if (fn.size() >= (1u << 28)) { err = "too many triangles for the leaf encoding"; return hipSuccess; }
+            };
+            std::atomic<size_t> next{0};
+            auto work = [&] { for (size_t k; (k = next.fetch_add(1)) < chunks.size();) fill(chunks[k]); };
+            const size_t nThreads = chunks.size() < 8 ? chunks.size() : 8;
+            std::vector<std::thread> th;
+            try {
+                for (size_t t = 1; t < nThreads; t++) th.emplace_back(work);
+            } catch (...) { }      // (fewer threads: the caller's thread does the rest)
+            work();
+            for (auto& t : th) t.join();
+        }
+        phaseMs[0] = since(tPhase);
+        // Per mesh: the tree, then where its leaves' records go.  srcOf[j] = rank of the triangle whose record becomes
+        // record j of the leaf array (-1: the blank that fills up an odd leaf); the records themselves are gathered and
+        // interleaved on the GPU (gatherLeafRecords).
+        std::vector<int32_t> srcOf;
+        srcOf.reserve(nRanked + nRanked / 8 + 16);
+        for (int b = 0; b < nBlas; b++) {
+            std::vector<BuildBox>& boxes = boxesOf[(size_t)b];
+            const size_t rankBase = walks[(size_t)b].rankBase;
             WideTree& tree = trees[b];
-            buildWideTree(boxes.data(), (int)boxes.size(), kLeafTris, tree);
+            {
+                // who builds this mesh's tree: the host's binned-SAH builder (the better tree) or, when the caller chose
+                // speed of upload (blasBuildMode / RTAMD_BLAS_BUILD=device; two-triangle leaves, 256 triangles or more), the GPU
+                int mode = blasBuildMode;
+                if (const char* sv = getenv("RTAMD_BLAS_BUILD")) mode = !strcmp(sv, "device") ? 2 : (!strcmp(sv, "host") ? 1 : mode);
+                const auto t0 = std::chrono::steady_clock::now();
+                if (mode == 2 && kLeafTris == 2 && boxes.size() >= 256) {
+                    if (!tlasBuilder && !(tlasBuilder = tlasDeviceCreate())) return hipErrorOutOfMemory;
+                    hipError_t be = blasDeviceBuild(tlasBuilder, boxes.data(), (int)boxes.size(), tree, stream);
+                    if (be != hipSuccess) return be;
+                    blasBuiltOnDevice++;
+                } else buildWideTree(boxes.data(), (int)boxes.size(), kLeafTris, tree);
+                blasBuildMs += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }
             if (tree.depth > maxDepth) maxDepth = tree.depth;
-            triBases[b] = (uint32_t)ft.size();
+            tPhase = clockNow();
+            triBases[b] = (uint32_t)srcOf.size();
             {
                 // every leaf starts a 128-byte line and is a whole number of lines (two 64-byte records each, the pair
                 // interleaved): an odd leaf ends with a blank record
-                std::vector<int32_t> leafAt(boxes.size() + 1, -1);      // first item of a leaf -> its number of items
+                const size_t nItems = boxes.size();
+                std::vector<int32_t> leafAt(nItems + 1, -1);      // first item of a leaf -> its number of items
                 for (const WideTree::Node& nd : tree.nodes)
                     for (int s4 = 0; s4 < 4; s4++)
                         if (nd.child[s4] < 0 && nd.child[s4] != widebvh::kEmpty) { const uint32_t code = (uint32_t)~nd.child[s4]; leafAt[code >> 3] = (int32_t)(code & 7u); }
-                std::vector<int32_t> newStart(boxes.size() + 1, 0);
-                FTri blank;
-                blank.a = make_float4(RT_INF, RT_INF, RT_INF, RT_INF); blank.b = make_float4(RT_INF, RT_INF, 0.f, 0.f);
-                blank.c = make_float4(0.f, 0.f, 0.f, 0.f); blank.d = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (size_t i = 0; i < boxes.size();) {
+                std::vector<int32_t> newStart(nItems + 1, 0);
+                for (size_t i = 0; i < nItems;) {
                     const int cnt = leafAt[i] > 0 ? leafAt[i] : 1;
-                    newStart[i] = (int32_t)(ft.size() - triBases[b]);
-                    const size_t first = ft.size();
-                    for (int k = 0; k < cnt; k++) ft.push_back(ranked[tree.order[i + (size_t)k]]);
-                    if (ft.size() & 1u) ft.push_back(blank);
-                    for (size_t at = first; at < ft.size(); at += 2) interleaveLeaf(&ft[at]);
+                    newStart[i] = (int32_t)(srcOf.size() - triBases[b]);
+                    for (int k = 0; k < cnt; k++) srcOf.push_back((int32_t)(rankBase + (size_t)tree.order[i + (size_t)k]));
+                    if (srcOf.size() & 1u) srcOf.push_back(-1);
                     i += (size_t)cnt;
                 }
                 for (WideTree::Node& nd : tree.nodes)
@@ -308,8 +404,13 @@ struct FastSceneHost {
                             nd.child[s4] = ~(int32_t)(((uint32_t)newStart[code >> 3] << 3) | (code & 7u));
                         }
             }
-            if (ft.size() >= (1u << 28)) { err = "too many triangles for the leaf encoding"; return hipSuccess; }
+            std::vector<BuildBox>().swap(boxes);
+            std::vector<int32_t>().swap(tree.order);
+            if (srcOf.size() >= (1u << 28)) { err = "too many triangles for the leaf encoding"; return hipSuccess; }
+            phaseMs[1] += since(tPhase);
         }
+        walks.clear();
+        tPhase = clockNow();
         // node indices: level by level over all trees (so that a prefix of the BLAS region holds the
         // top of every tree), behind the TLAS region
         {
@@ -353,9 +454,12 @@ struct FastSceneHost {
         blasUploaded = false;
         hipError_t e;
         nBlasOfScene = nBlas;
+        phaseMs[2] = since(tPhase);
+        tPhase = clockNow();
         {
-            // the tables of box bounds: sorted and distinct per BLAS and axis (the sorting on host threads, one set each)
-            sortPlaneSets(planeSets);
+            // the tables of box bounds: sorted and distinct per BLAS and axis
+            if (!tlasBuilder && !(tlasBuilder = tlasDeviceCreate())) return hipErrorOutOfMemory;
+            if ((e = sortPlaneSets(planeSets, tlasBuilder, stream)) != hipSuccess) return e;
             hPlanes.clear();
             hPlaneRange.assign(((size_t)nBlas + 1) * 6, 0);
             for (size_t k = 0; k < planeSets.size(); k++) {
@@ -367,15 +471,24 @@ struct FastSceneHost {
             planesUploaded = false;
             if (blasPlaneCount >= ((size_t)1 << 31)) { err = "too many box bounds for the table of planes"; return hipSuccess; }
         }
+        phaseMs[3] = since(tPhase);
+        tPhase = clockNow();
         hDemoted.assign((size_t)nBlas, 0);
         if ((e = guardBlas.ensure((size_t)nBlas)) != hipSuccess || (e = blasDemoted.ensure((size_t)nBlas)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(guardBlas.p, 0, (size_t)nBlas * sizeof(int32_t), stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(blasDemoted.p, 0, (size_t)nBlas * sizeof(int32_t), stream)) != hipSuccess) return e;
-        nTriRecords = (int32_t)ft.size(); nTriangles = (int32_t)fn.size();
-        if ((e = tris.put(ft, stream)) != hipSuccess) return e;
+        nTriRecords = (int32_t)srcOf.size(); nTriangles = (int32_t)fn.size();
+        if ((e = tris.ensure(srcOf.size())) != hipSuccess) return e;
+        if (!tlasBuilder && !(tlasBuilder = tlasDeviceCreate())) return hipErrorOutOfMemory;
+        if ((e = gatherLeafRecords(tlasBuilder, ranked.data(), ranked.size(), srcOf.data(), srcOf.size(), tris.p, stream)) != hipSuccess) return e;
         if ((e = nrms.put(fn, stream)) != hipSuccess) return e;
         if ((e = triOrig.put(orig, stream)) != hipSuccess) return e;
-        return hipStreamSynchronize(stream);   // ft / fn / orig die with this scope; the nodes go up with the TLAS
+        e = hipStreamSynchronize(stream);   // ranked / fn / orig die with this scope; the nodes go up with the TLAS
+        phaseMs[4] = since(tPhase);
+        if (getenv("RTAMD_VERBOSE"))
+            fprintf(stderr, "[rtamd] upload, meshes: walk of the caller's trees %.1f ms, tree builds %.1f ms (%d on the GPU), leaf records %.1f ms, node layout %.1f ms, box-bound tables %.1f ms, copies %.1f ms\n",
+                    phaseMs[0], blasBuildMs, blasBuiltOnDevice, phaseMs[1], phaseMs[2], phaseMs[3], phaseMs[4]);
+        return e;
     }
 
     // Re-build the TLAS behind the BLAS nodes and the per-object data.  Instances are kept
@@ -425,7 +538,7 @@ struct FastSceneHost {
                             if (n.Flags == 0) walk.push_back(n.Data[i]);
                         }
                 }
-                sortPlaneSets(sets);
+                (void)sortPlaneSets(sets);      // (on the host: cannot fail)
                 for (int ax = 0; ax < 3; ax++) {
                     hPlaneRange[tl + 2 * ax] = (int32_t)hPlanes.size();
                     hPlaneRange[tl + 2 * ax + 1] = (int32_t)sets[ax].size();

@@ -150,6 +150,7 @@ struct rtamd_ctx {
     int32_t lastGuardHits = 0, lastGuardRerendered = 0, demotedMeshes = 0;      // the culling guard: see rtamd_last_guard_stats
     float lastKernelMs = 0.f, lastHandoverMs = 0.f, lastTraceMs = 0.f;
     uint64_t lastRays = 0;
+    float lastUploadMs = 0.f;      // wall-clock time of the last rtamd_scene_upload (validation, re-pack, tree builds, copies)
 
     // Frames that return before they are complete (rtamd_render_begin / rtamd_render_wait): up to two in flight,
     // each with a working set of its own (the control block, the hand-over mask and list) and what
@@ -376,6 +377,23 @@ int rtamd_set_tlas_build(rtamd_ctx* c, int32_t mode) {
     return RTAMD_OK;
 }
 
+int rtamd_set_blas_build(rtamd_ctx* c, int32_t mode) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (mode < RTAMD_BLAS_BUILD_AUTO || mode > RTAMD_BLAS_BUILD_DEVICE) return fail(c, RTAMD_ERR_INVALID_ARG, "unknown BLAS build mode");
+    if (!c->subs.empty()) return multi::forEach(c, [&](rtamd_ctx* sub) { return rtamd_set_blas_build(sub, mode); });
+    c->fast.blasBuildMode = mode;
+    return RTAMD_OK;
+}
+
+int rtamd_last_upload_stats(const rtamd_ctx* c, float* upload_ms, float* tree_build_ms, int32_t* meshes_built_on_device) {
+    if (!c) return RTAMD_ERR_INVALID_ARG;
+    if (!c->subs.empty()) return rtamd_last_upload_stats(c->subs[0], upload_ms, tree_build_ms, meshes_built_on_device);
+    if (upload_ms) *upload_ms = c->lastUploadMs;
+    if (tree_build_ms) *tree_build_ms = c->fast.blasBuildMs;
+    if (meshes_built_on_device) *meshes_built_on_device = c->fast.blasBuiltOnDevice;
+    return RTAMD_OK;
+}
+
 int rtamd_tlas_info(const rtamd_ctx* c, int32_t* nodes, int32_t* levels, int32_t* built_on_device) {
     if (!c) return RTAMD_ERR_INVALID_ARG;
     if (!c->subs.empty()) return rtamd_tlas_info(c->subs[0], nodes, levels, built_on_device);
@@ -427,6 +445,7 @@ int rtamd_scene_upload(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas, cons
         return fail(c, RTAMD_ERR_INVALID_ARG, "empty scene buffer (the reference skips the dispatch when ObjectsCount == 0)");
     HIP_TRY(c, hipSetDevice(c->device));
     c->haveScene = false;
+    const auto uploadBegan = std::chrono::steady_clock::now();
     // offsets: exclusive prefix sums, BuildAccelerateStructureSystem.cs:105-117
     std::vector<int32_t> nodeCnt(nBlas), triCnt(nBlas), vertCnt(nBlas);
     for (int b = 0; b < nBlas; b++) {
@@ -445,6 +464,7 @@ int rtamd_scene_upload(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas, cons
                 return fail(c, RTAMD_ERR_BAD_INDEX, "triangle vertex index out of range");
         }
     }
+    const float validateMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - uploadBegan).count();
     c->nBlas = nBlas;
     c->hBlasOffsets.assign(blasOffsets, blasOffsets + nBlas);
     c->hTriOffsets.assign(triOffsets, triOffsets + nBlas);
@@ -461,6 +481,7 @@ int rtamd_scene_upload(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas, cons
 
     c->demotedMeshes = 0;
     std::string err;
+    const float rawCopyMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - uploadBegan).count() - validateMs;
     hipError_t e = c->fast.buildBottom(blasOffsets, blas, nodeCnt.data(), vtxOffsets, verts, triOffsets, tris,
                                        triCnt.data(), nBlas, nObjects, c->stream, err);
     if (e != hipSuccess) return failHip(c, e, "BLAS re-pack");
@@ -469,6 +490,9 @@ int rtamd_scene_upload(rtamd_ctx* c, const rtamd_node* tlas, int32_t nTlas, cons
     int rc = uploadTlasAndObjects(c, tlas, nTlas, objects, nObjects);
     if (rc) return rc;
     c->haveScene = true;
+    c->lastUploadMs = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - uploadBegan).count();
+    if (getenv("RTAMD_VERBOSE"))
+        fprintf(stderr, "[rtamd] upload: %.1f ms in all; validation %.1f ms, copies of the caller's arrays %.1f ms\n", c->lastUploadMs, validateMs, rawCopyMs);
     return RTAMD_OK;
     });
 }

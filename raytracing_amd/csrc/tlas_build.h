@@ -1,4 +1,5 @@
-// Device-side construction of the production kernel's top-level tree.
+// Device-side construction of the production kernel's trees: the top-level tree (below) and, for callers that
+// want a mesh's tree in milliseconds rather than the best one (RTAMD_BLAS_BUILD_DEVICE), a bottom-level tree.
 //
 // The reference rebuilds its TLAS on the CPU every frame (BuildAccelerateStructureSystem.cs:56-66,
 // TopLevelAccelerateStructure.cs:14-40) and uploads it; the production kernel does not walk that
@@ -12,6 +13,7 @@
 
 #include "fast_layout.h"
 #include "rtamd.h"
+#include "wide_bvh.h"
 
 namespace rt {
 
@@ -25,6 +27,24 @@ void tlasDeviceDestroy(TlasDeviceBuilder* b);
 // On return the stream has been synchronised and *nNodes / *depth describe the tree.
 hipError_t tlasDeviceBuild(TlasDeviceBuilder* b, const FInst* inst, int n, WNode* nodesOut, int reserve,
                            hipStream_t stream, int* nNodes, int* depth);
+
+// The bottom-level counterpart of buildWideTree (wide_bvh.h) for leaves of two: the tree over boxes[0..n) (host
+// memory) in the same form — nodes breadth first from the root, leaves as ~(start << 3 | count) into `order`.  The
+// reference bakes its bottom-level trees at edit time (Assets/Editor/RayTracing/Authoring/RayTraceableBaker.cs:75-149);
+// this builder is for meshes that change between frames.  Morton order, pairs of neighbours as leaves, binary radix
+// tree, collapse: the tree decides only the order of the tests, the leaf-slot boxes and triangles decide the hits.
+// The stream has been synchronised on return.
+hipError_t blasDeviceBuild(TlasDeviceBuilder* b, const BuildBox* boxes, int n, WideTree& out, hipStream_t stream);
+
+// The leaf array of the bottom-level trees from the triangles' records by rank (host memory): record j of `out`
+// (device memory, nRecords of them, an even number) is ranked[srcOf[j]], or a blank that no ray enters when
+// srcOf[j] < 0; pairs of records are stored interleaved, component by component (see FastSceneHost::buildBottom).
+// The stream has been synchronised on return.
+hipError_t gatherLeafRecords(TlasDeviceBuilder* b, const FTri* ranked, size_t nRanked, const int32_t* srcOf, size_t nRecords, FTri* out,
+                             hipStream_t stream);
+
+// values[0..n) (host memory, no NaN) sorted ascending by the GPU's radix sort, in place.
+hipError_t sortFloatsOnDevice(TlasDeviceBuilder* b, float* values, size_t n, hipStream_t stream);
 
 // Fills inst[r] / shade[r] for r in [0, n) from the caller's TLAS and object array as they lie in
 // device memory: instance r is the one in leaf slot (slotOf[r] & 3) of TLAS node (slotOf[r] >> 2);

@@ -1,4 +1,7 @@
-// Device-side construction of the production kernel's top-level tree (interface: tlas_build.h).
+// Device-side construction of the production kernel's trees (interface: tlas_build.h): the top-level tree over the
+// instances, per frame, and — where the caller asks for it — the bottom-level tree of a mesh at upload.  The kernels
+// are shared; what a leaf is (one instance / two triangles that are neighbours in Morton order) and what a finished
+// node looks like (WNode / WideTree::Node) are policies (InstLeaves, PairLeaves; WNodeOut, WideOut).
 //
 // Steps, all on the caller's stream:
 //   kTlasInit       bounds of the centroids := empty, parent of the root := none
@@ -20,6 +23,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "tlas_build.h"
+#include "wide_bvh.h"
 
 namespace rt {
 
@@ -63,6 +67,68 @@ __device__ __forceinline__ float halfArea(const Box3& b) {
     return a == a ? a : 0.f;
 }
 
+// Leaves of the top-level tree: one instance each.  prim(i) = box of input item i; after the sort leaf k is the item
+// at sorted position k.
+struct InstLeaves {
+    const FInst* inst;
+    const uint32_t* vals;
+    static constexpr int kStride = 1;
+    __device__ __forceinline__ Box3 prim(uint32_t i) const { return instBox(inst, i); }
+    __device__ __forceinline__ Box3 leaf(int k) const { return instBox(inst, vals[k]); }
+    __device__ __forceinline__ int32_t code(int k) const { return ~(int32_t)(vals[k] | kInstanceBit); }
+};
+// Leaves of a bottom-level tree: the triangles at sorted positions 2k and 2k + 1 (the last leaf of an odd mesh holds
+// one).  The leaf's box is the union of its triangles' leaf-slot boxes; its code is that of WideTree
+// (~(first position << 3 | count)).
+struct PairLeaves {
+    const BuildBox* boxes;
+    const uint32_t* vals;
+    int nPrims;
+    static constexpr int kStride = 2;
+    __device__ __forceinline__ Box3 prim(uint32_t i) const {
+        const BuildBox bb = boxes[i];
+        Box3 b;
+        b.lx = bb.lo[0]; b.ly = bb.lo[1]; b.lz = bb.lo[2]; b.hx = bb.hi[0]; b.hy = bb.hi[1]; b.hz = bb.hi[2];
+        return b;
+    }
+    __device__ __forceinline__ Box3 leaf(int k) const {
+        const Box3 a = prim(vals[2 * k]);
+        return 2 * k + 1 < nPrims ? unite(a, prim(vals[2 * k + 1])) : a;
+    }
+    __device__ __forceinline__ int32_t code(int k) const {
+        return ~(int32_t)(((uint32_t)(2 * k) << 3) | (2 * k + 1 < nPrims ? 2u : 1u));
+    }
+};
+// Finished 4-wide nodes: the production kernel's own record, or the host builder's (whose trees the upload code
+// lays out together with those built on the host).
+struct WNodeOut {
+    WNode* out;
+    static constexpr int32_t kEmpty = kEmptyChild;
+    __device__ __forceinline__ void write(int wi, const Box3* bx, const int32_t* code) const {
+        WNode w;
+        w.lx = make_float4(bx[0].lx, bx[1].lx, bx[2].lx, bx[3].lx); w.hx = make_float4(bx[0].hx, bx[1].hx, bx[2].hx, bx[3].hx);
+        w.ly = make_float4(bx[0].ly, bx[1].ly, bx[2].ly, bx[3].ly); w.hy = make_float4(bx[0].hy, bx[1].hy, bx[2].hy, bx[3].hy);
+        w.lz = make_float4(bx[0].lz, bx[1].lz, bx[2].lz, bx[3].lz); w.hz = make_float4(bx[0].hz, bx[1].hz, bx[2].hz, bx[3].hz);
+        w.child = make_int4(code[0], code[1], code[2], code[3]);
+        w.pad = make_int4(0, 0, 0, 0);
+        out[wi] = w;
+    }
+};
+struct WideOut {
+    WideTree::Node* out;
+    static constexpr int32_t kEmpty = widebvh::kEmpty;
+    __device__ __forceinline__ void write(int wi, const Box3* bx, const int32_t* code) const {
+        WideTree::Node w;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            w.lo[s][0] = bx[s].lx; w.lo[s][1] = bx[s].ly; w.lo[s][2] = bx[s].lz;
+            w.hi[s][0] = bx[s].hx; w.hi[s][1] = bx[s].hy; w.hi[s][2] = bx[s].hz;
+            w.child[s] = code[s];
+        }
+        out[wi] = w;
+    }
+};
+
 __global__ void kTlasInit(uint32_t* bounds, int32_t* parentInner, int32_t* result) {
     const int t = threadIdx.x;
     if (t < 3) bounds[t] = 0xffffffffu;
@@ -70,11 +136,12 @@ __global__ void kTlasInit(uint32_t* bounds, int32_t* parentInner, int32_t* resul
     if (t == 0) { parentInner[0] = -1; result[0] = 0; result[1] = 0; }
 }
 
-__global__ __launch_bounds__(kThreads) void kTlasBounds(const FInst* inst, int n, uint32_t* bounds) {
+template <typename Leaves>
+__global__ __launch_bounds__(kThreads) void kTlasBounds(Leaves lv, int n, uint32_t* bounds) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     float lo[3] = {kInf, kInf, kInf}, hi[3] = {-kInf, -kInf, -kInf};
     if (i < n) {
-        const Box3 b = instBox(inst, (uint32_t)i);
+        const Box3 b = lv.prim((uint32_t)i);
         lo[0] = hi[0] = centre(b.lx, b.hx);
         lo[1] = hi[1] = centre(b.ly, b.hy);
         lo[2] = hi[2] = centre(b.lz, b.hz);
@@ -112,11 +179,12 @@ __device__ __forceinline__ uint32_t quantise(float c, float lo, float scale) {
     return q >= 2097151.0f ? 2097151u : (uint32_t)q;
 }
 
-__global__ __launch_bounds__(kThreads) void kTlasMorton(const FInst* inst, int n, const uint32_t* bounds, uint64_t* keys,
+template <typename Leaves>
+__global__ __launch_bounds__(kThreads) void kTlasMorton(Leaves lv, int n, const uint32_t* bounds, uint64_t* keys,
                                                         uint32_t* vals) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n) return;
-    const Box3 b = instBox(inst, (uint32_t)i);
+    const Box3 b = lv.prim((uint32_t)i);
     const float lx = fromOrderedBits(bounds[0]), ly = fromOrderedBits(bounds[1]), lz = fromOrderedBits(bounds[2]);
     const float extent = fmaxf(fmaxf(fromOrderedBits(bounds[3]) - lx, fromOrderedBits(bounds[4]) - ly), fromOrderedBits(bounds[5]) - lz);
     const float scale = extent > 0.f ? 2097152.0f / extent : 0.f;
@@ -127,31 +195,32 @@ __global__ __launch_bounds__(kThreads) void kTlasMorton(const FInst* inst, int n
     vals[i] = (uint32_t)i;
 }
 
-// length of the common prefix of the codes at sorted positions i and j (-1 outside the array)
-__device__ __forceinline__ int commonPrefix(const uint64_t* keys, int n, int i, int j) {
+// length of the common prefix of the codes of leaves i and j (-1 outside the array); leaf k has the code at sorted
+// position k * stride (a leaf of several items: that of its first)
+__device__ __forceinline__ int commonPrefix(const uint64_t* keys, int n, int stride, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    const uint64_t a = keys[i], b = keys[j];
+    const uint64_t a = keys[(size_t)i * stride], b = keys[(size_t)j * stride];
     if (a == b) return 64 + __clz((uint32_t)(i ^ j));
     return __clzll((long long)(a ^ b));
 }
 
 // children: >= 0 binary inner node, < 0: ~(sorted position of a leaf)
-__global__ __launch_bounds__(kThreads) void kTlasHierarchy(const uint64_t* keys, int n, int32_t* left, int32_t* right,
+__global__ __launch_bounds__(kThreads) void kTlasHierarchy(const uint64_t* keys, int n, int stride, int32_t* left, int32_t* right,
                                                            int32_t* parentInner, int32_t* parentLeaf) {
     const int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n - 1) return;
-    const int d = commonPrefix(keys, n, i, i + 1) - commonPrefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
-    const int dMin = commonPrefix(keys, n, i, i - d);
+    const int d = commonPrefix(keys, n, stride, i, i + 1) - commonPrefix(keys, n, stride, i, i - 1) >= 0 ? 1 : -1;
+    const int dMin = commonPrefix(keys, n, stride, i, i - d);
     int lMax = 2;
-    while (commonPrefix(keys, n, i, i + lMax * d) > dMin) lMax <<= 1;
+    while (commonPrefix(keys, n, stride, i, i + lMax * d) > dMin) lMax <<= 1;
     int l = 0;
     for (int t = lMax >> 1; t >= 1; t >>= 1)
-        if (commonPrefix(keys, n, i, i + (l + t) * d) > dMin) l += t;
+        if (commonPrefix(keys, n, stride, i, i + (l + t) * d) > dMin) l += t;
     const int j = i + l * d;
-    const int dNode = commonPrefix(keys, n, i, j);
+    const int dNode = commonPrefix(keys, n, stride, i, j);
     int s = 0;
     for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
-        if (commonPrefix(keys, n, i, i + (s + t) * d) > dNode) s += t;
+        if (commonPrefix(keys, n, stride, i, i + (s + t) * d) > dNode) s += t;
         if (t <= 1) break;
     }
     const int gamma = i + s * d + (d < 0 ? -1 : 0);
@@ -176,12 +245,13 @@ __device__ __forceinline__ Box3 loadBoxCoherent(const float4* blo, const float4*
     return b;
 }
 
-__global__ __launch_bounds__(kThreads) void kTlasRefit(const FInst* inst, const uint32_t* vals, int n, const int32_t* left,
+template <typename Leaves>
+__global__ __launch_bounds__(kThreads) void kTlasRefit(Leaves lv, int n, const int32_t* left,
                                                        const int32_t* right, const int32_t* parentInner,
                                                        const int32_t* parentLeaf, float4* blo, float4* bhi, int32_t* flags) {
     const int k = blockIdx.x * kThreads + threadIdx.x;
     if (k >= n) return;
-    Box3 box = instBox(inst, vals[k]);
+    Box3 box = lv.leaf(k);
     int32_t me = ~k;
     int32_t p = parentLeaf[k];
     // every inner node is reached by exactly two threads; the walk ends at the root at the latest
@@ -191,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void kTlasRefit(const FInst* inst, const 
         if (atomicAdd(&flags[p], 1) == 0) return;      // the other child is not ready: its thread goes on
         __threadfence();
         const int32_t other = left[p] == me ? right[p] : left[p];
-        const Box3 ob = other >= 0 ? loadBoxCoherent(blo, bhi, other) : instBox(inst, vals[~other]);
+        const Box3 ob = other >= 0 ? loadBoxCoherent(blo, bhi, other) : lv.leaf(~other);
         box = unite(box, ob);
         blo[p] = make_float4(box.lx, box.ly, box.lz, 0.f);
         bhi[p] = make_float4(box.hx, box.hy, box.hz, 0.f);
@@ -201,34 +271,38 @@ __global__ __launch_bounds__(kThreads) void kTlasRefit(const FInst* inst, const 
 }
 
 
-__device__ __forceinline__ Box3 childBox(const FInst* inst, const uint32_t* vals, const float4* blo, const float4* bhi, int32_t c) {
+template <typename Leaves>
+__device__ __forceinline__ Box3 childBox(const Leaves& lv, const float4* blo, const float4* bhi, int32_t c) {
     if (c >= 0) {
         const float4 lo = blo[c], hi = bhi[c];
         Box3 b;
         b.lx = lo.x; b.ly = lo.y; b.lz = lo.z; b.hx = hi.x; b.hy = hi.y; b.hz = hi.z;
         return b;
     }
-    return instBox(inst, vals[~c]);
+    return lv.leaf(~c);
 }
 
 // result[0] = number of 4-wide nodes, result[1] = number of levels
-__global__ __launch_bounds__(kCollapseThreads) void kTlasCollapse(const FInst* inst, const uint32_t* vals, int n, const int32_t* left,
+template <typename Leaves, typename Out>
+__global__ __launch_bounds__(kCollapseThreads) void kTlasCollapse(Leaves lv, int n, const int32_t* left,
                                                                    const int32_t* right, const float4* blo, const float4* bhi,
-                                                                   WNode* out, int reserve, int32_t* queueA, int32_t* queueB,
+                                                                   Out out, int reserve, int32_t* queueA, int32_t* queueB,
                                                                    int32_t* result) {
     __shared__ int32_t waveTotal[kCollapseThreads / 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     if (n == 1) {
         if (tid == 0) {
-            const Box3 b = instBox(inst, 0u);
-            WNode w;
-            w.lx = make_float4(b.lx, kInf, kInf, kInf); w.hx = make_float4(b.hx, kInf, kInf, kInf);
-            w.ly = make_float4(b.ly, kInf, kInf, kInf); w.hy = make_float4(b.hy, kInf, kInf, kInf);
-            w.lz = make_float4(b.lz, kInf, kInf, kInf); w.hz = make_float4(b.hz, kInf, kInf, kInf);
-            w.child = make_int4(~(int32_t)(0u | kInstanceBit), kEmptyChild, kEmptyChild, kEmptyChild);
-            w.pad = make_int4(0, 0, 0, 0);
-            out[0] = w;
+            Box3 bx[4];
+            int32_t code[4];
+            bx[0] = lv.leaf(0);
+            code[0] = lv.code(0);
+#pragma unroll
+            for (int s = 1; s < 4; s++) {
+                bx[s].lx = bx[s].ly = bx[s].lz = bx[s].hx = bx[s].hy = bx[s].hz = kInf;
+                code[s] = Out::kEmpty;
+            }
+            out.write(0, bx, code);
             result[0] = 1; result[1] = 1;
         }
         return;
@@ -255,9 +329,9 @@ __global__ __launch_bounds__(kCollapseThreads) void kTlasCollapse(const FInst* i
                 for (int iter = 0; iter < 2; iter++) {
                     int pick = -1;
                     float bestA = -1.f;
-                    if (s0 >= 0) { const float a = halfArea(childBox(inst, vals, blo, bhi, s0)); if (a > bestA) { bestA = a; pick = 0; } }
-                    if (s1 >= 0) { const float a = halfArea(childBox(inst, vals, blo, bhi, s1)); if (a > bestA) { bestA = a; pick = 1; } }
-                    if (ns > 2 && s2 >= 0) { const float a = halfArea(childBox(inst, vals, blo, bhi, s2)); if (a > bestA) { bestA = a; pick = 2; } }
+                    if (s0 >= 0) { const float a = halfArea(childBox(lv, blo, bhi, s0)); if (a > bestA) { bestA = a; pick = 0; } }
+                    if (s1 >= 0) { const float a = halfArea(childBox(lv, blo, bhi, s1)); if (a > bestA) { bestA = a; pick = 1; } }
+                    if (ns > 2 && s2 >= 0) { const float a = halfArea(childBox(lv, blo, bhi, s2)); if (a > bestA) { bestA = a; pick = 2; } }
                     if (pick < 0) break;
                     const int32_t c = pick == 0 ? s0 : (pick == 1 ? s1 : s2);
                     const int32_t l = left[c], r = right[c];
@@ -292,23 +366,15 @@ __global__ __launch_bounds__(kCollapseThreads) void kTlasCollapse(const FInst* i
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     if (s < ns) {
-                        bx[s] = childBox(inst, vals, blo, bhi, sl[s]);
+                        bx[s] = childBox(lv, blo, bhi, sl[s]);
                         if (sl[s] >= 0) { if (pos < n) nxt[pos] = sl[s]; code[s] = nextBase + pos; pos++; }
-                        else code[s] = ~(int32_t)(vals[~sl[s]] | kInstanceBit);
+                        else code[s] = lv.code(~sl[s]);
                     } else {
                         bx[s].lx = bx[s].ly = bx[s].lz = bx[s].hx = bx[s].hy = bx[s].hz = kInf;    // never entered
-                        code[s] = kEmptyChild;
+                        code[s] = Out::kEmpty;
                     }
                 }
-                if (wi < reserve) {
-                    WNode w;
-                    w.lx = make_float4(bx[0].lx, bx[1].lx, bx[2].lx, bx[3].lx); w.hx = make_float4(bx[0].hx, bx[1].hx, bx[2].hx, bx[3].hx);
-                    w.ly = make_float4(bx[0].ly, bx[1].ly, bx[2].ly, bx[3].ly); w.hy = make_float4(bx[0].hy, bx[1].hy, bx[2].hy, bx[3].hy);
-                    w.lz = make_float4(bx[0].lz, bx[1].lz, bx[2].lz, bx[3].lz); w.hz = make_float4(bx[0].hz, bx[1].hz, bx[2].hz, bx[3].hz);
-                    w.child = make_int4(code[0], code[1], code[2], code[3]);
-                    w.pad = make_int4(0, 0, 0, 0);
-                    out[wi] = w;
-                }
+                if (wi < reserve) out.write(wi, bx, code);
             }
             nextCount += total;
             __syncthreads();     // waveTotal is reused; nxt is read by the whole workgroup in the next level
@@ -353,6 +419,23 @@ __global__ __launch_bounds__(kThreads) void kTlasPack(const rtamd_node* tlas, co
     shade[r] = fs;
 }
 
+// Leaf records of the bottom-level trees: record j of the output is the record of the triangle with rank srcOf[j]
+// (a blank that no ray enters when srcOf[j] < 0), and every pair of records (2p, 2p + 1) is stored component by
+// component — lo.xyz, hi.xyz, v0.xyz, e1.xyz, e2.xyz, rank of record 2p beside those of record 2p + 1 — so that the
+// traversal kernels test both with two-wide instructions.  One thread per output float.
+__global__ __launch_bounds__(kThreads) void kGatherLeafRecords(const float* ranked, const int32_t* srcOf, size_t nFloats, float* out) {
+    const size_t idx = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= nFloats) return;
+    const size_t pair = idx >> 5;
+    const int within = (int)(idx & 31u), j = within >> 1, k = within & 1;
+    const int component = j < 6 ? j : (j < 15 ? j + 1 : 6);      // (the rank, float 6 of a record, goes last)
+    const int32_t src = srcOf[2 * pair + (size_t)k];
+    float v;
+    if (src >= 0) v = ranked[(size_t)src * 16 + (size_t)component];
+    else v = component < 6 ? kInf : 0.f;
+    out[idx] = v;
+}
+
 template <typename T>
 struct Buf {
     T* p = nullptr;
@@ -375,7 +458,7 @@ struct TlasDeviceBuilder {
     Buf<uint32_t> valsA, valsB, bounds;
     Buf<int32_t> left, right, parentInner, parentLeaf, flags, queueA, queueB, result;
     Buf<float4> blo, bhi;
-    Buf<unsigned char> temp;
+    Buf<unsigned char> temp, prims, wide;      // sort scratch; a mesh's boxes and its finished nodes (bottom-level builds)
 };
 
 TlasDeviceBuilder* tlasDeviceCreate() { return new (std::nothrow) TlasDeviceBuilder(); }
@@ -384,7 +467,7 @@ void tlasDeviceDestroy(TlasDeviceBuilder* b) {
     if (!b) return;
     b->keysA.release(); b->keysB.release(); b->valsA.release(); b->valsB.release(); b->bounds.release();
     b->left.release(); b->right.release(); b->parentInner.release(); b->parentLeaf.release(); b->flags.release();
-    b->queueA.release(); b->queueB.release(); b->result.release(); b->blo.release(); b->bhi.release(); b->temp.release();
+    b->queueA.release(); b->queueB.release(); b->result.release(); b->blo.release(); b->bhi.release(); b->temp.release(); b->prims.release(); b->wide.release();
     delete b;
 }
 
@@ -396,10 +479,16 @@ hipError_t tlasPackInstances(const rtamd_node* tlas, const rtamd_object_property
     return hipGetLastError();
 }
 
-hipError_t tlasDeviceBuild(TlasDeviceBuilder* b, const FInst* inst, int n, WNode* nodesOut, int reserve, hipStream_t stream,
-                           int* nNodes, int* depth) {
-    if (!b || !inst || !nodesOut || n < 1 || reserve < (n > 2 ? n - 1 : 1)) return hipErrorInvalidValue;
-    const size_t N = (size_t)n;
+namespace {
+
+// The shared sequence.  nPrims items, nLeaves = ceil(nPrims / Leaves::kStride) leaves; `pre` reads the items by input
+// index (no sorted order yet), `post(vals)` makes the policy that knows the sorted order.  On return the stream has
+// been synchronised.
+template <typename Leaves, typename Out, typename MakeSorted>
+hipError_t buildOnDevice(TlasDeviceBuilder* b, const Leaves& pre, MakeSorted post, int nPrims, Out out, int reserve,
+                         hipStream_t stream, int* nNodes, int* depth) {
+    const size_t N = (size_t)nPrims;
+    const int nLeaves = (nPrims + Leaves::kStride - 1) / Leaves::kStride;
     hipError_t e;
     if ((e = b->keysA.ensure(N)) != hipSuccess || (e = b->keysB.ensure(N)) != hipSuccess || (e = b->valsA.ensure(N)) != hipSuccess ||
         (e = b->valsB.ensure(N)) != hipSuccess || (e = b->bounds.ensure(8)) != hipSuccess || (e = b->left.ensure(N)) != hipSuccess ||
@@ -408,23 +497,30 @@ hipError_t tlasDeviceBuild(TlasDeviceBuilder* b, const FInst* inst, int n, WNode
         (e = b->result.ensure(4)) != hipSuccess || (e = b->blo.ensure(N)) != hipSuccess || (e = b->bhi.ensure(N)) != hipSuccess)
         return e;
     const unsigned grid = (unsigned)((N + kThreads - 1) / kThreads);
+    const unsigned leafGrid = (unsigned)(((size_t)nLeaves + kThreads - 1) / kThreads);
     hipLaunchKernelGGL(kTlasInit, dim3(1), dim3(64), 0, stream, b->bounds.p, b->parentInner.p, b->result.p);
     const uint32_t* vals = b->valsA.p;
-    if (n > 1) {
+    if (nPrims > 1) {
         if ((e = hipMemsetAsync(b->flags.p, 0, N * sizeof(int32_t), stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL(kTlasBounds, dim3(grid), dim3(kThreads), 0, stream, inst, n, b->bounds.p);
-        hipLaunchKernelGGL(kTlasMorton, dim3(grid), dim3(kThreads), 0, stream, inst, n, b->bounds.p, b->keysA.p, b->valsA.p);
+        hipLaunchKernelGGL((kTlasBounds<Leaves>), dim3(grid), dim3(kThreads), 0, stream, pre, nPrims, b->bounds.p);
+        hipLaunchKernelGGL((kTlasMorton<Leaves>), dim3(grid), dim3(kThreads), 0, stream, pre, nPrims, b->bounds.p, b->keysA.p, b->valsA.p);
         size_t tempBytes = 0;
-        if ((e = rocprim::radix_sort_pairs(nullptr, tempBytes, b->keysA.p, b->keysB.p, b->valsA.p, b->valsB.p, (unsigned)n, 0u, 63u, stream)) != hipSuccess) return e;
+        if ((e = rocprim::radix_sort_pairs(nullptr, tempBytes, b->keysA.p, b->keysB.p, b->valsA.p, b->valsB.p, (unsigned)nPrims, 0u, 63u, stream)) != hipSuccess) return e;
         if ((e = b->temp.ensure(tempBytes)) != hipSuccess) return e;
-        if ((e = rocprim::radix_sort_pairs(b->temp.p, tempBytes, b->keysA.p, b->keysB.p, b->valsA.p, b->valsB.p, (unsigned)n, 0u, 63u, stream)) != hipSuccess) return e;
+        if ((e = rocprim::radix_sort_pairs(b->temp.p, tempBytes, b->keysA.p, b->keysB.p, b->valsA.p, b->valsB.p, (unsigned)nPrims, 0u, 63u, stream)) != hipSuccess) return e;
         vals = b->valsB.p;
-        hipLaunchKernelGGL(kTlasHierarchy, dim3(grid), dim3(kThreads), 0, stream, b->keysB.p, n, b->left.p, b->right.p, b->parentInner.p, b->parentLeaf.p);
-        hipLaunchKernelGGL(kTlasRefit, dim3(grid), dim3(kThreads), 0, stream, inst, vals, n, b->left.p, b->right.p, b->parentInner.p, b->parentLeaf.p,
+    } else {
+        const uint32_t zero = 0;
+        if ((e = hipMemcpyAsync(b->valsA.p, &zero, sizeof zero, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    }
+    const Leaves lv = post(vals);
+    if (nLeaves > 1) {
+        hipLaunchKernelGGL(kTlasHierarchy, dim3(leafGrid), dim3(kThreads), 0, stream, b->keysB.p, nLeaves, Leaves::kStride, b->left.p, b->right.p, b->parentInner.p, b->parentLeaf.p);
+        hipLaunchKernelGGL((kTlasRefit<Leaves>), dim3(leafGrid), dim3(kThreads), 0, stream, lv, nLeaves, b->left.p, b->right.p, b->parentInner.p, b->parentLeaf.p,
                            b->blo.p, b->bhi.p, b->flags.p);
     }
-    hipLaunchKernelGGL(kTlasCollapse, dim3(1), dim3(kCollapseThreads), 0, stream, inst, vals, n, b->left.p, b->right.p, b->blo.p, b->bhi.p,
-                       nodesOut, reserve, b->queueA.p, b->queueB.p, b->result.p);
+    hipLaunchKernelGGL((kTlasCollapse<Leaves, Out>), dim3(1), dim3(kCollapseThreads), 0, stream, lv, nLeaves, b->left.p, b->right.p, b->blo.p, b->bhi.p,
+                       out, reserve, b->queueA.p, b->queueB.p, b->result.p);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     int32_t res[2] = {0, 0};
     if ((e = hipMemcpyAsync(res, b->result.p, sizeof(res), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
@@ -433,6 +529,71 @@ hipError_t tlasDeviceBuild(TlasDeviceBuilder* b, const FInst* inst, int n, WNode
     *nNodes = res[0];
     *depth = res[1];
     return hipSuccess;
+}
+
+}  // namespace
+
+hipError_t tlasDeviceBuild(TlasDeviceBuilder* b, const FInst* inst, int n, WNode* nodesOut, int reserve, hipStream_t stream,
+                           int* nNodes, int* depth) {
+    if (!b || !inst || !nodesOut || n < 1 || reserve < (n > 2 ? n - 1 : 1)) return hipErrorInvalidValue;
+    const InstLeaves pre{inst, nullptr};
+    return buildOnDevice(b, pre, [inst](const uint32_t* vals) { return InstLeaves{inst, vals}; }, n, WNodeOut{nodesOut}, reserve, stream, nNodes, depth);
+}
+
+hipError_t blasDeviceBuild(TlasDeviceBuilder* b, const BuildBox* boxes, int n, WideTree& out, hipStream_t stream) {
+    out.nodes.clear(); out.order.clear(); out.depth = 0;
+    if (!b || !boxes || n < 1) return hipErrorInvalidValue;
+    const int nLeaves = (n + 1) / 2;
+    const int reserve = nLeaves > 2 ? nLeaves - 1 : 1;
+    hipError_t e;
+    if ((e = b->prims.ensure((size_t)n * sizeof(BuildBox))) != hipSuccess || (e = b->wide.ensure((size_t)reserve * sizeof(WideTree::Node))) != hipSuccess) return e;
+    BuildBox* dBoxes = reinterpret_cast<BuildBox*>(b->prims.p);
+    WideTree::Node* dNodes = reinterpret_cast<WideTree::Node*>(b->wide.p);
+    if ((e = hipMemcpyAsync(dBoxes, boxes, (size_t)n * sizeof(BuildBox), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    const PairLeaves pre{dBoxes, nullptr, n};
+    int nNodes = 0, depth = 0;
+    if ((e = buildOnDevice(b, pre, [dBoxes, n](const uint32_t* vals) { return PairLeaves{dBoxes, vals, n}; }, n, WideOut{dNodes}, reserve, stream, &nNodes, &depth)) != hipSuccess)
+        return e;
+    try {
+        out.nodes.resize((size_t)nNodes);
+        out.order.resize((size_t)n);
+    } catch (...) { out.nodes.clear(); out.order.clear(); return hipErrorOutOfMemory; }
+    if ((e = hipMemcpyAsync(out.nodes.data(), dNodes, (size_t)nNodes * sizeof(WideTree::Node), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    const uint32_t* sorted = n > 1 ? b->valsB.p : b->valsA.p;
+    if ((e = hipMemcpyAsync(out.order.data(), sorted, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    out.depth = depth;
+    return hipStreamSynchronize(stream);
+}
+
+hipError_t gatherLeafRecords(TlasDeviceBuilder* b, const FTri* ranked, size_t nRanked, const int32_t* srcOf, size_t nRecords, FTri* out,
+                             hipStream_t stream) {
+    if (!b || !ranked || !srcOf || !out || (nRecords & 1u)) return hipErrorInvalidValue;
+    if (nRecords == 0) return hipSuccess;
+    hipError_t e;
+    if ((e = b->prims.ensure(nRanked * sizeof(FTri))) != hipSuccess || (e = b->queueA.ensure(nRecords)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(b->prims.p, ranked, nRanked * sizeof(FTri), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(b->queueA.p, srcOf, nRecords * sizeof(int32_t), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    const size_t nFloats = nRecords * 16;
+    hipLaunchKernelGGL(kGatherLeafRecords, dim3((unsigned)((nFloats + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
+                       reinterpret_cast<const float*>(b->prims.p), b->queueA.p, nFloats, reinterpret_cast<float*>(out));
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return hipStreamSynchronize(stream);      // (the host arrays may go once this returns)
+}
+
+hipError_t sortFloatsOnDevice(TlasDeviceBuilder* b, float* values, size_t n, hipStream_t stream) {
+    if (!b || !values || n >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    if (n < 2) return hipSuccess;
+    hipError_t e;
+    if ((e = b->keysA.ensure((n + 1) / 2)) != hipSuccess || (e = b->keysB.ensure((n + 1) / 2)) != hipSuccess) return e;
+    float* in = reinterpret_cast<float*>(b->keysA.p);
+    float* out = reinterpret_cast<float*>(b->keysB.p);
+    if ((e = hipMemcpyAsync(in, values, n * sizeof(float), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    size_t tempBytes = 0;
+    if ((e = rocprim::radix_sort_keys(nullptr, tempBytes, in, out, (unsigned)n, 0u, 32u, stream)) != hipSuccess) return e;
+    if ((e = b->temp.ensure(tempBytes)) != hipSuccess) return e;
+    if ((e = rocprim::radix_sort_keys(b->temp.p, tempBytes, in, out, (unsigned)n, 0u, 32u, stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(values, out, n * sizeof(float), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    return hipStreamSynchronize(stream);
 }
 
 }  // namespace rt
