@@ -360,24 +360,55 @@ struct FastSceneHost {
         // interleaved on the GPU (gatherLeafRecords).
         std::vector<int32_t> srcOf;
         srcOf.reserve(nRanked + nRanked / 8 + 16);
+        {
+            // Who builds a mesh's tree: the host's binned-SAH builder (the better tree) or, when the caller chose speed
+            // of upload (blasBuildMode / RTAMD_BLAS_BUILD=device; two-triangle leaves, 256 triangles or more), the GPU.
+            // The host's builds run side by side, largest mesh first, on up to widebvh::kMaxThreads threads in all
+            // (a large mesh's build spreads over threads by itself; a scene of many small meshes needs this).
+            int mode = blasBuildMode;
+            if (const char* sv = getenv("RTAMD_BLAS_BUILD")) mode = !strcmp(sv, "device") ? 2 : (!strcmp(sv, "host") ? 1 : mode);
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<int> onHost;
+            for (int b = 0; b < nBlas; b++) {
+                std::vector<BuildBox>& boxes = boxesOf[(size_t)b];
+                if (mode == 2 && kLeafTris == 2 && boxes.size() >= 256) {
+                    if (!tlasBuilder && !(tlasBuilder = tlasDeviceCreate())) return hipErrorOutOfMemory;
+                    hipError_t be = blasDeviceBuild(tlasBuilder, boxes.data(), (int)boxes.size(), trees[(size_t)b], stream);
+                    if (be != hipSuccess) return be;
+                    blasBuiltOnDevice++;
+                } else onHost.push_back(b);
+            }
+            std::sort(onHost.begin(), onHost.end(), [&](int x, int y) {
+                return boxesOf[(size_t)x].size() != boxesOf[(size_t)y].size() ? boxesOf[(size_t)x].size() > boxesOf[(size_t)y].size() : x < y;
+            });
+            std::atomic<size_t> next{0};
+            std::atomic<int> atWork{0};
+            std::atomic<bool> failed{false};
+            auto work = [&] {
+                for (size_t k; (k = next.fetch_add(1)) < onHost.size();) {
+                    const int b = onHost[k];
+                    try { buildWideTree(boxesOf[(size_t)b].data(), (int)boxesOf[(size_t)b].size(), kLeafTris, trees[(size_t)b], &atWork); }
+                    catch (...) { failed.store(true); }
+                }
+            };
+            std::vector<std::thread> th;
+            try {
+                // (a helper only where a second mesh waits and a thread is free: atWork counts this thread too)
+                atWork.fetch_add(1);
+                for (size_t t = 1; t < onHost.size() && t < (size_t)widebvh::kMaxThreads; t++) {
+                    if (atWork.fetch_add(1) >= widebvh::kMaxThreads) { atWork.fetch_sub(1); break; }
+                    th.emplace_back([&] { work(); atWork.fetch_sub(1); });
+                }
+            } catch (...) { atWork.fetch_sub(1); }
+            work();
+            for (auto& t : th) t.join();
+            if (failed.load()) throw std::bad_alloc();
+            blasBuildMs += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
         for (int b = 0; b < nBlas; b++) {
             std::vector<BuildBox>& boxes = boxesOf[(size_t)b];
             const size_t rankBase = walks[(size_t)b].rankBase;
             WideTree& tree = trees[b];
-            {
-                // who builds this mesh's tree: the host's binned-SAH builder (the better tree) or, when the caller chose
-                // speed of upload (blasBuildMode / RTAMD_BLAS_BUILD=device; two-triangle leaves, 256 triangles or more), the GPU
-                int mode = blasBuildMode;
-                if (const char* sv = getenv("RTAMD_BLAS_BUILD")) mode = !strcmp(sv, "device") ? 2 : (!strcmp(sv, "host") ? 1 : mode);
-                const auto t0 = std::chrono::steady_clock::now();
-                if (mode == 2 && kLeafTris == 2 && boxes.size() >= 256) {
-                    if (!tlasBuilder && !(tlasBuilder = tlasDeviceCreate())) return hipErrorOutOfMemory;
-                    hipError_t be = blasDeviceBuild(tlasBuilder, boxes.data(), (int)boxes.size(), tree, stream);
-                    if (be != hipSuccess) return be;
-                    blasBuiltOnDevice++;
-                } else buildWideTree(boxes.data(), (int)boxes.size(), kLeafTris, tree);
-                blasBuildMs += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            }
             if (tree.depth > maxDepth) maxDepth = tree.depth;
             tPhase = clockNow();
             triBases[b] = (uint32_t)srcOf.size();
