@@ -34,6 +34,8 @@ namespace Script.RayTracing
             int nBlas, void* objects, int nObjects);
         [DllImport(Lib)] public static extern int rtamd_scene_refresh_objects(IntPtr ctx, void* tlas, int nTlas, void* objects, int nObjects);
         [DllImport(Lib)] public static extern int rtamd_set_tlas_build(IntPtr ctx, int mode);      // 0 auto, 1 host, 2 device
+        [DllImport(Lib)] public static extern int rtamd_set_blas_build(IntPtr ctx, int mode);      // 0 auto (host), 1 host, 2 device: who builds the meshes' trees at the next upload
+        [DllImport(Lib)] public static extern int rtamd_last_upload_stats(IntPtr ctx, out float uploadMs, out float treeBuildMs, out int meshesBuiltOnDevice);
         [DllImport(Lib)] public static extern int rtamd_tlas_info(IntPtr ctx, out int nodes, out int levels, out int builtOnDevice);
         [DllImport(Lib)] public static extern int rtamd_sky_upload(IntPtr ctx, void* rgba32f, int w, int h);
         [DllImport(Lib)] public static extern int rtamd_render(IntPtr ctx, FrameCBuffer* frame, ExtParams* ext, int w, int h, void* outRgba, void* outPrimId);
