@@ -8,7 +8,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, ".")
-import torch  # noqa: E402,F401  (before the library: see INTEGRATION.md)
+import torch  # noqa: E402,F401  (before the library is loaded: torch brings its own HIP runtime, and of two runtimes in one process its own sees no GPU)
 
 from raytracing_amd import backend, scenes, types as T  # noqa: E402
 
