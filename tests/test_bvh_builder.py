@@ -58,6 +58,38 @@ def test_sah_builder_same_format(oracle):
     assert nodes[1]["Flags"] == 0
 
 
+def test_sah_builder_large_input_on_threads(oracle):
+    """150 000 boxes: subtrees of 16 384 items and more are built by threads of their own and spliced in.  The
+    tree must pass the integrity check (every primitive once, child boxes inside their parents') and must not depend
+    on how the threads were scheduled: two builds give the same set of leaves with the same boxes."""
+    rs = np.random.RandomState(5)
+    n = 150_000
+    d = rs.normal(size=(n, 3))
+    c = (d / np.linalg.norm(d, axis=1, keepdims=True) * rs.uniform(0.9, 1.1, size=(n, 1))).astype(np.float32)
+    e = rs.uniform(0.001, 0.02, size=(n, 3)).astype(np.float32)
+    aabbs = np.zeros(n, dtype=T.AABB)
+    aabbs["Min"] = c - e
+    aabbs["Max"] = c + e
+
+    def leaves(nodes):
+        leaf = nodes[nodes["Flags"] != 0]
+        out = []
+        for k in range(4):
+            m = leaf["Data"][:, k] >= 0
+            out.append(np.stack([leaf["Data"][m, k].astype(np.float64), leaf["Lx"][m, k], leaf["Hx"][m, k], leaf["Ly"][m, k],
+                                 leaf["Hy"][m, k], leaf["Lz"][m, k], leaf["Hz"][m, k]], 1))
+        a = np.concatenate(out)
+        return a[np.argsort(a[:, 0])]
+
+    first = H.BoundingVolumeHierarchy.BuildSah(aabbs)
+    assert oracle.check_integrity(first, n) == 0
+    second = H.BoundingVolumeHierarchy.BuildSah(aabbs)
+    assert len(first) == len(second)
+    a, b = leaves(first), leaves(second)
+    assert a.shape == b.shape == (n, 7) and np.array_equal(a, b)
+    assert np.array_equal(a[:, 1], aabbs["Min"][:, 0].astype(np.float64)) and np.array_equal(a[:, 6], aabbs["Max"][:, 2].astype(np.float64))
+
+
 def test_integrity_checker_detects_damage(oracle):
     nodes, aabbs, _ = _build(H.Mesh.uv_sphere(16, 8, 0.5))
     n = len(aabbs)
