@@ -517,6 +517,9 @@ struct FastSceneHost {
         e = hipStreamSynchronize(stream);   // ranked / fn / orig die with this scope; the nodes go up with the TLAS
         phaseMs[4] = since(tPhase);
         if (getenv("RTAMD_VERBOSE"))
+            fprintf(stderr, "[rtamd] upload, meshes: %d triangles in %d leaf records (%.1f %% blanks), %zu nodes\n", nTriangles, nTriRecords,
+                    nTriRecords ? 100.0 * (nTriRecords - nTriangles) / nTriRecords : 0.0, nBlasNodes);
+        if (getenv("RTAMD_VERBOSE"))
             fprintf(stderr, "[rtamd] upload, meshes: walk of the caller's trees %.1f ms, tree builds %.1f ms (%d on the GPU), leaf records %.1f ms, node layout %.1f ms, box-bound tables %.1f ms, copies %.1f ms\n",
                     phaseMs[0], blasBuildMs, blasBuiltOnDevice, phaseMs[1], phaseMs[2], phaseMs[3], phaseMs[4]);
         return e;
