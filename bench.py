@@ -196,6 +196,33 @@ def ref_mode_frames(rt, frame, W, Hh, out, frames=100):
             "value": r["rays"] / ms / 1e3, "unit": "Mrays/s"}
 
 
+def frames_in_flight(rt, frame, W, Hh, out, spp, args, dev, steps):
+    """The same step through rtamd_render_begin / rtamd_render_wait, two frames in flight (a host that renders frame
+    after frame, RayTracingPass.cs:62-109): the next frame's kernel runs while the last paths of this one are
+    handed over and summed.  Reported beside the blocking figure, which stays the line's value."""
+    import torch
+    from raytracing_amd import types as T
+    outs = [out, torch.zeros_like(out)]
+    kw = dict(mode=T.MODE_PT, spp=spp, max_bounces=args.bounces, seed=args.seed)
+    try:
+        rt.ExecuteBegin(frame, W, Hh, out_rgba=outs[0], **kw)
+        rt.ExecuteWait()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rays = 0
+        rt.ExecuteBegin(frame, W, Hh, out_rgba=outs[0], **kw)
+        for k in range(1, steps):
+            rt.ExecuteBegin(frame, W, Hh, out_rgba=outs[k & 1], **kw)
+            rays += rt.ExecuteWait()["rays"]
+        rays += rt.ExecuteWait()["rays"]
+        torch.cuda.synchronize()
+        e = time.perf_counter() - t0
+    except Exception as ex:      # (a frame too large for one batch of paths: the blocking call is the only way)
+        return {"unavailable": str(ex)}
+    return {"value": rays / e / 1e6, "unit": "Mrays/s", "ms_per_step": e / steps * 1e3, "steps": steps,
+            "what": "rtamd_render_begin / rtamd_render_wait, two frames in flight, same frames as the blocking steps"}
+
+
 def pt_workload(rt, name, args, dev, kernel_name, steps):
     """One more path-traced workload on the same context: scene up, timed steps, roofline."""
     import torch
@@ -211,6 +238,7 @@ def pt_workload(rt, name, args, dev, kernel_name, steps):
     e, a, last = timed_steps(step, steps, 1, torch.cuda.synchronize, lambda: None)
     rec = {"workload": f"{desc}, 1920x1080, {spp} spp, {args.bounces} bounces", "value": a["rays"] / e / 1e6,
            "unit": "Mrays/s", "ms_per_step": e / steps * 1e3, "steps": steps,
+           "two_frames_in_flight": frames_in_flight(rt, frame, 1920, 1080, out, spp, args, dev, max(steps, 3)),
            "roofline": None if args.no_counters else roofline_for(
                rt, frame, 1920, 1080, out, args, name, spp, a["trace_ms"] / steps,
                a["kernel_ms"] / steps - a["handover_ms"] / steps - a["trace_ms"] / steps, a["handover_ms"] / steps, last, kernel_name)}
@@ -223,6 +251,7 @@ def secondary_workloads(rt, frame, out, args, dev, kernel_name, roofline):
     from raytracing_amd import types as T
     steps = max(2, args.steps)
     others = {}
+    others["mesh_two_frames_in_flight"] = frames_in_flight(rt, frame, 1920, 1080, out, args.spp or DEFAULT_SPP["mesh"], args, dev, max(steps, 3))
     ref = {"what": "REF mode = the reference shader's own image (primary ray + one mirror ray per covered pixel, RayTracingShader.compute:413-429): "
                    "wall-clock milliseconds per blocking rtamd_render call, frame in device memory; handover_ms is the part spent in the "
                    "reference-order kernel on the pixels the production kernel passed on"}
