@@ -103,6 +103,21 @@ def build_testhost(force=False):
     return TESTHOST
 
 
+def build_examples(force=False):
+    """examples/render_scene.c, a C99 program over the two headers alone (gcc, linked against both libraries):
+    the boundary used from the language a P/Invoke binding mirrors.  Skipped where the examples are absent."""
+    src = os.path.join(ROOT, "examples", "render_scene.c")
+    if not os.path.isfile(src):
+        return None
+    exe = os.path.join(ROOT, "examples", "_build", "render_scene")
+    deps = [src, build_device(), build_host(), os.path.join(INC, "rtamd.h"), os.path.join(INC, "rtamd_host.h")]
+    if force or _newer(exe, deps):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        _run([os.environ.get("CC", "gcc"), "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + INC, src, "-o", exe,
+              "-L" + LIB, "-lrtamd", "-lrtamd_host", "-Wl,-rpath,$ORIGIN/../../raytracing_amd/lib"])
+    return exe
+
+
 def build_oracle(force=False):
     """The checker, twice: the declared arithmetic (every `/` of the shader a true division), and the
     reciprocal-multiplication reading (used only to count what the choice between the two moves)."""
@@ -118,7 +133,7 @@ def build_oracle(force=False):
 
 
 def build_all(force=False):
-    return build_device(force), build_host(force), build_testhost(force), build_oracle(force)
+    return build_device(force), build_host(force), build_testhost(force), build_oracle(force), build_examples(force)
 
 
 if __name__ == "__main__":
