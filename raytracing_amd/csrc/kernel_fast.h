@@ -1078,6 +1078,17 @@ __global__ __launch_bounds__(kBlockThreads, RT_MIN_WAVES) void kFast(rtamd_frame
     if (lane == 0 && r) atomicAdd(a.rayCount, r);
 }
 
+// How a budget of LDS node slots is shared: the top-level tree gets what the bottom-level trees leave, and at least
+// its share of the budget (RTAMD_HOT_TLAS_SHARE, percent) as far as it has nodes.
+inline void hotNodeRanges(const FastSceneHost& fs, int budget, int32_t& hotTlas, int32_t& hotBlas) {
+    static const int share = [] { const char* s = getenv("RTAMD_HOT_TLAS_SHARE"); const int v = s ? atoi(s) : 50; return v < 0 ? 0 : (v > 100 ? 100 : v); }();
+    const int nb = fs.nBlasNodes < (size_t)budget ? (int)fs.nBlasNodes : budget;
+    int tl = budget - nb > budget * share / 100 ? budget - nb : budget * share / 100;
+    if (tl > fs.nTlasNodes) tl = fs.nTlasNodes;
+    hotTlas = tl;
+    hotBlas = budget - tl < nb ? budget - tl : nb;
+}
+
 struct FastLaunchConfig {
     // refillBelow / nodeMin = 0: chosen per scene in launchFast
     int blocksPerCU = 1, refillBelow = 0, nodeMin = 0, leafGroupMin = 20;
@@ -1181,12 +1192,8 @@ inline hipError_t launchFast(FastSceneHost& fs, const Sky& sky, const RenderArgs
     }
     // LDS budget: the whole TLAS if it leaves half of the room (or more, when the BLAS trees are small) to the BLAS tops
     {
-        const int nb = fs.nBlasNodes < (size_t)kHotNodes ? (int)fs.nBlasNodes : kHotNodes;
-        int tl = kHotNodes - nb > kHotNodes / 2 ? kHotNodes - nb : kHotNodes / 2;
-        if (tl > fs.nTlasNodes) tl = fs.nTlasNodes;
-        sc.hotTlas = tl;
+        hotNodeRanges(fs, kHotNodes, sc.hotTlas, sc.hotBlas);
         sc.blasBase = fs.tlasReserve;
-        sc.hotBlas = kHotNodes - tl < nb ? kHotNodes - tl : nb;
     }
 
     if (a.mode == RTAMD_MODE_PT && (a.outIds || a.outT)) {

@@ -697,13 +697,7 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
     sc.stackSpill = fs.stackSpill.p;
     sc.spillMax = kSpillMax;
     sc.blasBase = fs.tlasReserve;
-    auto hotRanges = [&](int budget, int32_t& hotTlas, int32_t& hotBlas) {
-        const int nb = fs.nBlasNodes < (size_t)budget ? (int)fs.nBlasNodes : budget;
-        int tl = budget - nb > budget / 2 ? budget - nb : budget / 2;
-        if (tl > fs.nTlasNodes) tl = fs.nTlasNodes;
-        hotTlas = tl;
-        hotBlas = budget - tl < nb ? budget - tl : nb;
-    };
+    auto hotRanges = [&](int budget, int32_t& hotTlas, int32_t& hotBlas) { hotNodeRanges(fs, budget, hotTlas, hotBlas); };
     hotRanges(kHotNodes, sc.hotTlas, sc.hotBlas);
 
     if (a.outIds || a.outT) {
