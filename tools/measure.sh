@@ -1,7 +1,8 @@
 #!/bin/bash
 # One measuring session on the GPU box: kernel-trace profiles and counter passes of the bench step for the mesh
 # (headline), spheres and 50 M-instanced workloads, and the per-phase lane statistics of the path-pool kernel.
-# Usage: tools/measure.sh <tag>      (results under gpurun_out/: prof_<tag>_*, pmc_<tag>_*, <tag>_phase_lanes.txt)
+# Usage: tools/measure.sh <tag>      (results under gpurun_out/: prof_<tag>_*, pmc_<tag>_*, <tag>_phase_lanes.txt;
+#        afterwards, here: python tools/stamp_profiles.py <tag> copies what is kept into profiles/)
 set -e
 TAG=${1:-run}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
