@@ -395,7 +395,7 @@ def main():
 
     (buf, frame, sky), desc = build_workload(args.workload, W, Hh, args.tree)
     if inproc:
-        rt = backend.RayTracingPass(devices=list(range(args.gpus)))
+        rt = backend.RayTracingPass(devices=[0] * args.gpus if rehearse else list(range(args.gpus)))
     else:
         rt = backend.RayTracingPass(dev_index)
         # kernels, the RCCL all-reduce and the normalisation all run on torch's current stream
