@@ -228,9 +228,9 @@ int rtamd_set_tlas_build(rtamd_ctx* ctx, int32_t mode);
  * bottom-level trees at edit time (Assets/Editor/RayTracing/Authoring/RayTraceableBaker.cs:75-149) and the caller
  * still passes those: they give every triangle its leaf-slot box and its place in the visiting order, which decide
  * hits and ties.  The hierarchy the production kernels walk is rebuilt: on the host (binned SAH on up to 8 threads,
- * the tree that traces fastest; AUTO and HOST) or on the GPU (Morton order, neighbours paired into leaves, binary
- * radix tree collapsed to 4-wide nodes: milliseconds per million triangles, for meshes that change between frames;
- * meshes below 256 triangles stay with the host builder).  Which triangle a ray hits does not depend on the choice.
+ * the tree that traces fastest; AUTO and HOST) or on the GPU (Morton order, binary radix tree over the triangles,
+ * sibling triangles paired into leaves, collapsed to 4-wide nodes: 25 ms per million triangles against 85, frames
+ * trace 4-8 % slower; for meshes that change between frames; meshes below 256 triangles stay with the host builder).  Which triangle a ray hits does not depend on the choice.
  * Takes effect at the next rtamd_scene_upload. */
 #define RTAMD_BLAS_BUILD_AUTO 0
 #define RTAMD_BLAS_BUILD_HOST 1

@@ -31,8 +31,9 @@ hipError_t tlasDeviceBuild(TlasDeviceBuilder* b, const FInst* inst, int n, WNode
 // The bottom-level counterpart of buildWideTree (wide_bvh.h) for leaves of two: the tree over boxes[0..n) (host
 // memory) in the same form — nodes breadth first from the root, leaves as ~(start << 3 | count) into `order`.  The
 // reference bakes its bottom-level trees at edit time (Assets/Editor/RayTracing/Authoring/RayTraceableBaker.cs:75-149);
-// this builder is for meshes that change between frames.  Morton order, pairs of neighbours as leaves, binary radix
-// tree, collapse: the tree decides only the order of the tests, the leaf-slot boxes and triangles decide the hits.
+// this builder is for meshes that change between frames.  Morton order, binary radix tree over the triangles (two
+// sibling triangles make one leaf), collapse: the tree decides only the order of the tests, the leaf-slot boxes and
+// triangles decide the hits.
 // The stream has been synchronised on return.
 hipError_t blasDeviceBuild(TlasDeviceBuilder* b, const BuildBox* boxes, int n, WideTree& out, hipStream_t stream);
 

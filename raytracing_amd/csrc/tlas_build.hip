@@ -1,7 +1,7 @@
 // Device-side construction of the production kernel's trees (interface: tlas_build.h): the top-level tree over the
 // instances, per frame, and — where the caller asks for it — the bottom-level tree of a mesh at upload.  The kernels
-// are shared; what a leaf is (one instance / two triangles that are neighbours in Morton order) and what a finished
-// node looks like (WNode / WideTree::Node) are policies (InstLeaves, PairLeaves; WNodeOut, WideOut).
+// are shared; what a leaf is (one instance / one triangle, or two that are siblings in the radix tree) and what a
+// finished node looks like (WNode / WideTree::Node) are policies (InstLeaves, TriLeaves; WNodeOut, WideOut).
 //
 // Steps, all on the caller's stream:
 //   kTlasInit       bounds of the centroids := empty, parent of the root := none
@@ -77,28 +77,28 @@ struct InstLeaves {
     __device__ __forceinline__ Box3 leaf(int k) const { return instBox(inst, vals[k]); }
     __device__ __forceinline__ int32_t code(int k) const { return ~(int32_t)(vals[k] | kInstanceBit); }
 };
-// Leaves of a bottom-level tree: the triangles at sorted positions 2k and 2k + 1 (the last leaf of an odd mesh holds
-// one).  The leaf's box is the union of its triangles' leaf-slot boxes; its code is that of WideTree
-// (~(first position << 3 | count)).
-struct PairLeaves {
+// Leaves of a bottom-level tree: the radix tree is built over single triangles, and a binary node whose two children
+// are both triangles becomes a leaf of two (they are neighbours in Morton order and nothing in the tree is closer to
+// either: one 128-byte line of the leaf array); a triangle whose sibling is a subtree stays a leaf of one.  Codes
+// are those of WideTree (~(first position << 3 | count)).
+struct TriLeaves {
     const BuildBox* boxes;
     const uint32_t* vals;
     int nPrims;
-    static constexpr int kStride = 2;
+    static constexpr int kStride = 1;
     __device__ __forceinline__ Box3 prim(uint32_t i) const {
         const BuildBox bb = boxes[i];
         Box3 b;
         b.lx = bb.lo[0]; b.ly = bb.lo[1]; b.lz = bb.lo[2]; b.hx = bb.hi[0]; b.hy = bb.hi[1]; b.hz = bb.hi[2];
         return b;
     }
-    __device__ __forceinline__ Box3 leaf(int k) const {
-        const Box3 a = prim(vals[2 * k]);
-        return 2 * k + 1 < nPrims ? unite(a, prim(vals[2 * k + 1])) : a;
-    }
-    __device__ __forceinline__ int32_t code(int k) const {
-        return ~(int32_t)(((uint32_t)(2 * k) << 3) | (2 * k + 1 < nPrims ? 2u : 1u));
-    }
+    __device__ __forceinline__ Box3 leaf(int k) const { return prim(vals[k]); }
+    __device__ __forceinline__ int32_t code(int k) const { return ~(int32_t)(((uint32_t)k << 3) | 1u); }
+    __device__ __forceinline__ int32_t pairCode(int k) const { return ~(int32_t)(((uint32_t)k << 3) | 2u); }
 };
+template <typename Leaves> struct MergesPairs { static constexpr bool value = false; };
+template <> struct MergesPairs<TriLeaves> { static constexpr bool value = true; };
+
 // Finished 4-wide nodes: the production kernel's own record, or the host builder's (whose trees the upload code
 // lays out together with those built on the host).
 struct WNodeOut {
@@ -291,12 +291,34 @@ __global__ __launch_bounds__(kCollapseThreads) void kTlasCollapse(Leaves lv, int
     __shared__ int32_t waveTotal[kCollapseThreads / 64];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    // does child c get a 4-wide node of its own?  (a binary node, unless it is a pair of leaves that becomes one leaf)
+    auto opens = [&](int32_t c) -> bool {
+        if (c < 0) return false;
+        if (MergesPairs<Leaves>::value) return left[c] >= 0 || right[c] >= 0;
+        return true;
+    };
     if (n == 1) {
         if (tid == 0) {
             Box3 bx[4];
             int32_t code[4];
             bx[0] = lv.leaf(0);
             code[0] = lv.code(0);
+#pragma unroll
+            for (int s = 1; s < 4; s++) {
+                bx[s].lx = bx[s].ly = bx[s].lz = bx[s].hx = bx[s].hy = bx[s].hz = kInf;
+                code[s] = Out::kEmpty;
+            }
+            out.write(0, bx, code);
+            result[0] = 1; result[1] = 1;
+        }
+        return;
+    }
+    if (MergesPairs<Leaves>::value && n == 2) {
+        if (tid == 0) {
+            Box3 bx[4];
+            int32_t code[4];
+            bx[0] = unite(lv.leaf(0), lv.leaf(1));
+            if constexpr (MergesPairs<Leaves>::value) code[0] = lv.pairCode(0); else code[0] = Out::kEmpty;
 #pragma unroll
             for (int s = 1; s < 4; s++) {
                 bx[s].lx = bx[s].ly = bx[s].lz = bx[s].hx = bx[s].hy = bx[s].hz = kInf;
@@ -329,9 +351,9 @@ __global__ __launch_bounds__(kCollapseThreads) void kTlasCollapse(Leaves lv, int
                 for (int iter = 0; iter < 2; iter++) {
                     int pick = -1;
                     float bestA = -1.f;
-                    if (s0 >= 0) { const float a = halfArea(childBox(lv, blo, bhi, s0)); if (a > bestA) { bestA = a; pick = 0; } }
-                    if (s1 >= 0) { const float a = halfArea(childBox(lv, blo, bhi, s1)); if (a > bestA) { bestA = a; pick = 1; } }
-                    if (ns > 2 && s2 >= 0) { const float a = halfArea(childBox(lv, blo, bhi, s2)); if (a > bestA) { bestA = a; pick = 2; } }
+                    if (opens(s0)) { const float a = halfArea(childBox(lv, blo, bhi, s0)); if (a > bestA) { bestA = a; pick = 0; } }
+                    if (opens(s1)) { const float a = halfArea(childBox(lv, blo, bhi, s1)); if (a > bestA) { bestA = a; pick = 1; } }
+                    if (ns > 2 && opens(s2)) { const float a = halfArea(childBox(lv, blo, bhi, s2)); if (a > bestA) { bestA = a; pick = 2; } }
                     if (pick < 0) break;
                     const int32_t c = pick == 0 ? s0 : (pick == 1 ? s1 : s2);
                     const int32_t l = left[c], r = right[c];
@@ -340,7 +362,7 @@ __global__ __launch_bounds__(kCollapseThreads) void kTlasCollapse(Leaves lv, int
                     ns++;
                 }
             }
-            const int k = act ? ((s0 >= 0) + (s1 >= 0) + (ns > 2 && s2 >= 0) + (ns > 3 && s3 >= 0)) : 0;
+            const int k = act ? (opens(s0) + opens(s1) + (ns > 2 && opens(s2)) + (ns > 3 && opens(s3))) : 0;
             // exclusive scan of k over the workgroup
             int incl = k;
 #pragma unroll
@@ -367,7 +389,8 @@ __global__ __launch_bounds__(kCollapseThreads) void kTlasCollapse(Leaves lv, int
                 for (int s = 0; s < 4; s++) {
                     if (s < ns) {
                         bx[s] = childBox(lv, blo, bhi, sl[s]);
-                        if (sl[s] >= 0) { if (pos < n) nxt[pos] = sl[s]; code[s] = nextBase + pos; pos++; }
+                        if (opens(sl[s])) { if (pos < n) nxt[pos] = sl[s]; code[s] = nextBase + pos; pos++; }
+                        else if (sl[s] >= 0) { if constexpr (MergesPairs<Leaves>::value) code[s] = lv.pairCode(~left[sl[s]]); else code[s] = Out::kEmpty; }
                         else code[s] = lv.code(~sl[s]);
                     } else {
                         bx[s].lx = bx[s].ly = bx[s].lz = bx[s].hx = bx[s].hy = bx[s].hz = kInf;    // never entered
@@ -543,16 +566,16 @@ hipError_t tlasDeviceBuild(TlasDeviceBuilder* b, const FInst* inst, int n, WNode
 hipError_t blasDeviceBuild(TlasDeviceBuilder* b, const BuildBox* boxes, int n, WideTree& out, hipStream_t stream) {
     out.nodes.clear(); out.order.clear(); out.depth = 0;
     if (!b || !boxes || n < 1) return hipErrorInvalidValue;
-    const int nLeaves = (n + 1) / 2;
+    const int nLeaves = n;
     const int reserve = nLeaves > 2 ? nLeaves - 1 : 1;
     hipError_t e;
     if ((e = b->prims.ensure((size_t)n * sizeof(BuildBox))) != hipSuccess || (e = b->wide.ensure((size_t)reserve * sizeof(WideTree::Node))) != hipSuccess) return e;
     BuildBox* dBoxes = reinterpret_cast<BuildBox*>(b->prims.p);
     WideTree::Node* dNodes = reinterpret_cast<WideTree::Node*>(b->wide.p);
     if ((e = hipMemcpyAsync(dBoxes, boxes, (size_t)n * sizeof(BuildBox), hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-    const PairLeaves pre{dBoxes, nullptr, n};
     int nNodes = 0, depth = 0;
-    if ((e = buildOnDevice(b, pre, [dBoxes, n](const uint32_t* vals) { return PairLeaves{dBoxes, vals, n}; }, n, WideOut{dNodes}, reserve, stream, &nNodes, &depth)) != hipSuccess)
+    const TriLeaves pre{dBoxes, nullptr, n};
+    if ((e = buildOnDevice(b, pre, [dBoxes, n](const uint32_t* vals) { return TriLeaves{dBoxes, vals, n}; }, n, WideOut{dNodes}, reserve, stream, &nNodes, &depth)) != hipSuccess)
         return e;
     try {
         out.nodes.resize((size_t)nNodes);

@@ -19,6 +19,13 @@ def _render(p, frame, w, h, **kw):
     return rgba.cpu().numpy(), ids.cpu().numpy(), t.cpu().numpy(), r["rays"]
 
 
+@pytest.fixture(autouse=True)
+def _host_builder_afterwards(gpu_pass):
+    """(the context is shared by the whole session: the tests that follow get the default builder back)"""
+    yield
+    gpu_pass.SetBlasBuild("auto")
+
+
 def _scene(name, w, h):
     from raytracing_amd import scenes
     if name == "soup":
