@@ -16,10 +16,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--tris", type=int, default=1_000_000)
 ap.add_argument("--spp", type=int, default=32)
 ap.add_argument("--scene", default="mesh", choices=["mesh", "instanced", "spheres"])
+ap.add_argument("--procedural", action="store_true", help="mesh scene from displaced spheres of any triangle count instead of the reference's models")
 a = ap.parse_args()
 w, h = 1920, 1080
 if a.scene == "mesh":
-    buf, frame, sky = scenes.mesh_scene(w, h, target_tris=a.tris)
+    buf, frame, sky = scenes.mesh_scene(w, h, target_tris=a.tris, procedural=a.procedural)
 elif a.scene == "instanced":
     buf, frame, sky = scenes.instanced_scene(w, h)
 else:
