@@ -1,8 +1,9 @@
 """REF-mode frames only (for a kernel trace of the reference shader's own image): python tools/ref_frames.py [mesh|spheres] [width height] [frames]"""
+import os
 import sys
 import time
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch  # noqa: E402
 
 from raytracing_amd import backend, scenes, types as T  # noqa: E402

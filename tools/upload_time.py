@@ -2,12 +2,13 @@
 rtamd_scene_upload, its tree-building part, and what the choice costs when tracing (PT, the bench's mesh scene).
     python tools/upload_time.py [--tris 1000000] [--spp 32]"""
 import argparse
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch  # noqa: E402,F401  (before the library is loaded: torch brings its own HIP runtime, and of two runtimes in one process its own sees no GPU)
 
 from raytracing_amd import backend, scenes, types as T  # noqa: E402
