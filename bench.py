@@ -185,13 +185,21 @@ def ref_mode_frames(rt, frame, W, Hh, out, frames=100):
     t0 = time.perf_counter()
     km = hm = 0.0
     r = None
+    each = []
     for _ in range(frames):
+        t1 = time.perf_counter()
         r = rt.Execute(frame, W, Hh, out_rgba=out, mode=T.MODE_REF)
+        each.append((time.perf_counter() - t1) * 1e3)
         km += r["kernel_ms"]
         hm += r["handover_ms"]
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / frames * 1e3
-    return {"resolution": [W, Hh], "frames": frames, "ms_per_render_call": ms, "kernels_ms": km / frames,
+    mean_ms = (time.perf_counter() - t0) / frames * 1e3
+    each.sort()
+    # (the median of the calls: on a fresh box one call in a few hundred takes tens of milliseconds on the host side,
+    # which a mean over 100 frames carries as +0.4 ms; mean and slowest call are reported beside it)
+    ms = each[len(each) // 2]
+    return {"resolution": [W, Hh], "frames": frames, "ms_per_render_call": ms, "ms_mean_call": mean_ms, "ms_slowest_call": each[-1],
+            "kernels_ms": km / frames,
             "handover_ms": hm / frames, "handover_pixels": r["handover_pixels"], "ray_segments": r["rays"],
             "value": r["rays"] / ms / 1e3, "unit": "Mrays/s"}
 
@@ -253,7 +261,7 @@ def secondary_workloads(rt, frame, out, args, dev, kernel_name, roofline):
     others = {}
     others["mesh_two_frames_in_flight"] = frames_in_flight(rt, frame, 1920, 1080, out, args.spp or DEFAULT_SPP["mesh"], args, dev, max(steps, 3))
     ref = {"what": "REF mode = the reference shader's own image (primary ray + one mirror ray per covered pixel, RayTracingShader.compute:413-429): "
-                   "wall-clock milliseconds per blocking rtamd_render call, frame in device memory; handover_ms is the part spent in the "
+                   "wall-clock milliseconds per blocking rtamd_render call (median of the timed calls; ms_mean_call and ms_slowest_call beside it), frame in device memory; handover_ms is the part spent in the "
                    "reference-order kernel on the pixels the production kernel passed on"}
     ref["mesh_1080p"] = ref_mode_frames(rt, frame, 1920, 1080, out)
     out4 = torch.zeros((2160, 3840, 4), dtype=torch.float32, device=dev)      # (same aspect: the same frame record)
