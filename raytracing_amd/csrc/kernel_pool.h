@@ -50,7 +50,7 @@ constexpr int kPoolChunk = 256;      // path indices a wave takes from the batch
 #define RT_POOL_HOT_NODES_BIG 164
 #endif
 constexpr int kPoolHotNodesBig = RT_POOL_HOT_NODES_BIG;   // the variant for large scenes: 18 KiB of nodes, and 32 KiB for the paths' throughput words instead
-constexpr int kPoolBigSceneNodes = 65536;                 // scenes with more nodes than this run the large-scene variant (RTAMD_POOL_BIG=0/1 overrides)
+constexpr int kPoolBigSceneNodes = 16384;                 // scenes with more nodes than this run the large-scene variant (RTAMD_POOL_BIG=0/1 overrides; the 50 M-instanced scene, 31 760 nodes: +1 %)
 constexpr int kPoolHotNodes = RT_POOL_HOT_NODES;   // LDS: 64 KiB stacks + 6 KiB queues + 40 KiB hit results and states + 50 KiB nodes
 
 struct PoolBatch {
