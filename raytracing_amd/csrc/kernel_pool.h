@@ -679,7 +679,12 @@ inline hipError_t launchPool(FastSceneHost& fs, PoolHost& ph, const Sky& sky, co
         // loads of the LDS lanes and of the others are separate instructions, a scene with at most twice the nodes
         // the copy holds — the random-spheres scene: about 480 — runs best on the first pair too: +2.4 %.)
         const bool allHot = fs.nBlasNodes + (size_t)fs.nTlasNodes <= 2 * (size_t)kPoolHotNodes;
-        if (cfg.refillBelow == 0) cfg.refillBelow = allHot ? 36 : (big ? 44 : 48);
+        // (a large scene of many instances — the 50 M-instanced one: 1 251 — mixes instance entries and triangle leaves
+        // in every leaf phase; there a small group of either kind is better served at once than kept waiting: group
+        // threshold 12 instead of 20 and refill below 48: +1.4 %; the 1M-triangle scene, 7 instances, loses 2 % with 12)
+        const bool manyInstances = big && fs.nInst >= 256;
+        if (manyInstances && !getenv("RTAMD_LEAF_GROUP_MIN")) cfg.leafGroupMin = 12;
+        if (cfg.refillBelow == 0) cfg.refillBelow = allHot ? 36 : (big ? (manyInstances ? 48 : 44) : 48);
         if (cfg.nodeMin == 0) {
             cfg.nodeMin = allHot ? 12 : (big ? 24 : 28);
             // a frame of one or two samples per pixel is over before the waves fall out of step: there the shorter
