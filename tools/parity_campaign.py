@@ -49,7 +49,7 @@ def main():
         if wl == "soup":
             # a new random scene per "camera"
             for ci in range(args.cameras):
-                buf, frame, sky = scenes.random_soup(w, h, seed=ci + (args.seed - 2025))
+                buf, frame, sky = scenes.random_soup(w, h, seed=ci + abs(args.seed - 2025))
                 rt.SetScene(buf)
                 rt.SetSkyBox(sky)
                 bad_total += compare(rt, wl, ci, frame, w, h, args.spp)
